@@ -1,0 +1,126 @@
+/*
+ * pwclo_ops.h -- C ABI of libpwclo_hip.so, the MI355X (gfx950) implementation of the
+ * PWCLO-Net point-cloud operator path.
+ *
+ * Drop-in boundary.  The reference's extension is split into C++ host files that check and
+ * allocate torch tensors and then call plain C++ launchers taking raw device pointers and
+ * 32-bit sizes.  Those nine launchers are the FFI of this path; section 1 exports them with the
+ * reference's exact names, argument order and meaning (extern "C"; the reference declares them
+ * at the cited lines inside its .cpp files, so relinking its host files against this library
+ * needs only `extern "C"` around those declarations -- see INTEGRATION.md).
+ *
+ * All pointers are device pointers on the current HIP device.  Tensors are dense, row-major
+ * ("contiguous" in the reference's CHECK_CONTIGUOUS sense), float = IEEE binary32, int = int32.
+ * Calls enqueue on the stream set by pwclo_set_stream() for the calling host thread (default:
+ * the null stream) and return without synchronising -- the reference launches on ATen's current
+ * stream the same way (e.g. group_points_gpu.cu:34).  No entry point allocates, frees or
+ * synchronises, so every call may be captured into a hipGraph.
+ *
+ * Errors.  The reference prints and calls exit(-1) when a launch fails (cuda_utils.h:30-39).
+ * This library never exits the process: it prints one line to stderr, records the failure in a
+ * per-thread sticky status readable through pwclo_last_error(), and skips the launch.  Host
+ * bindings must check pwclo_last_error() after a call and raise (ours do).
+ *
+ * Reference paths below are relative to
+ *   /root/reference/slam/models/Pointnet2_PyTorch/pointnet2_ops_lib/pointnet2_ops/_ext-src/src/
+ */
+#ifndef PWCLO_OPS_H
+#define PWCLO_OPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- 0. library state ------------------------------------------------------------------- */
+
+/* Version of this ABI (bumped on any signature change). */
+int pwclo_abi_version(void);
+
+/* Set / get the hipStream_t (passed as void*) used by the calling host thread's launches.
+ * Replaces at::cuda::getCurrentCUDAStream() inside the reference launchers. */
+void pwclo_set_stream(void *hip_stream);
+void *pwclo_get_stream(void);
+
+/* 0 = no error since the last pwclo_clear_error() on this thread, else a hipError_t value or
+ * one of the PWCLO_E* codes.  pwclo_last_error_message() returns a static thread-local string. */
+int pwclo_last_error(void);
+const char *pwclo_last_error_message(void);
+void pwclo_clear_error(void);
+
+#define PWCLO_EINVAL 10001  /* argument outside what the kernels support (message says which) */
+
+/* ---- 1. the nine reference launchers ------------------------------------------------------ */
+
+/* sampling.cpp:4-6 / sampling_gpu.cu:22-30.  out[b,c,j] = points[b,c,idx[b,j]].
+ * points (b,c,n) f32, idx (b,npoints) i32, out (b,c,npoints) f32. */
+void gather_points_kernel_wrapper(int b, int c, int n, int npoints, const float *points,
+                                  const int *idx, float *out);
+
+/* sampling.cpp:7-9 / sampling_gpu.cu:49-57.  grad_points[b,c,idx[b,j]] += grad_out[b,c,j];
+ * grad_points (b,c,n) must be zero-filled by the caller (sampling.cpp:51-53). */
+void gather_points_grad_kernel_wrapper(int b, int c, int n, int npoints, const float *grad_out,
+                                       const int *idx, float *grad_points);
+
+/* sampling.cpp:11-13 / sampling_gpu.cu:175-229.  Iterative furthest point sampling.
+ * dataset (b,n,3) f32; temp (b,n) f32 scratch pre-filled with 1e10 by the caller
+ * (sampling.cpp:74-76; this implementation keeps the running distances in registers and only
+ * requires temp to be a valid (b,n) buffer or NULL); idxs (b,m) i32.  Index 0 is always the
+ * first sample; points with x*x+y*y+z*z <= 1e-3 are never selected; ties are resolved exactly
+ * as the reference's block-of-opt_n_threads(n) tree reduction does ("FPS tie rule"). */
+void furthest_point_sampling_kernel_wrapper(int b, int n, int m, const float *dataset,
+                                            float *temp, int *idxs);
+
+/* group_points.cpp:4-6 / group_points_gpu.cu:30-39.  out[b,c,j,k] = points[b,c,idx[b,j,k]].
+ * points (b,c,n), idx (b,npoints,nsample) i32, out (b,c,npoints,nsample). */
+void group_points_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                 const float *points, const int *idx, float *out);
+
+/* group_points.cpp:8-10 / group_points_gpu.cu:66-75.  Scatter-add of grad_out (b,c,npoints,
+ * nsample) into zero-filled grad_points (b,c,n). */
+void group_points_grad_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                      const float *grad_out, const int *idx, float *grad_points);
+
+/* ball_query.cpp:4-6 / ball_query_gpu.cu:46-54.  For each centre new_xyz[b,j] the first
+ * `nsample` indices k (ascending) with |new_xyz-xyz[k]|^2 < radius^2; unfilled slots repeat the
+ * first hit; a centre without any hit leaves its slots untouched (caller zero-fills idx,
+ * ball_query.cpp:19-21).  new_xyz (b,m,3), xyz (b,n,3), idx (b,m,nsample) i32. */
+void query_ball_point_kernel_wrapper(int b, int n, int m, float radius, int nsample,
+                                     const float *new_xyz, const float *xyz, int *idx);
+
+/* interpolate.cpp:4-5 / interpolate_gpu.cu:61-68.  Three nearest `known` points of every
+ * `unknown` point: dist2 (b,n,3) squared distances ascending, idx (b,n,3); ties -> lower index;
+ * m < 3 leaves dist2 = +inf, idx = 0 in the unfilled slots. */
+void three_nn_kernel_wrapper(int b, int n, int m, const float *unknown, const float *known,
+                             float *dist2, int *idx);
+
+/* interpolate.cpp:6-8 / interpolate_gpu.cu:103-111.
+ * out[b,c,j] = sum_t points[b,c,idx[b,j,t]] * weight[b,j,t].  points (b,c,m), out (b,c,n). */
+void three_interpolate_kernel_wrapper(int b, int c, int m, int n, const float *points,
+                                      const int *idx, const float *weight, float *out);
+
+/* interpolate.cpp:9-12 / interpolate_gpu.cu:145-154.  Scatter-add of grad_out (b,c,n) * weight
+ * into zero-filled grad_points (b,c,m). */
+void three_interpolate_grad_kernel_wrapper(int b, int c, int n, int m, const float *grad_out,
+                                           const int *idx, const float *weight,
+                                           float *grad_points);
+
+/* ---- 2. native replacements of pure-PyTorch ops on the same path -------------------------- */
+
+/* Replaces pytorch_utils.py:12-49 (knn_point = dense distance + torch.topk).  For every query
+ * new_xyz[b,j] the `nsample` nearest points of xyz[b] in ascending key order, key =
+ * sqrtf(((dx*dx + dy*dy) + dz*dz) + 1e-8f) with dx = query - candidate, every operation rounded
+ * to binary32 (no contraction); equal keys -> lower index first.  xyz (b,n,3), new_xyz (b,s,3),
+ * idx (b,s,nsample) i32, dist (b,s,nsample) f32 or NULL.  Requires 1 <= nsample <= 64 and
+ * nsample <= n (else PWCLO_EINVAL). */
+void knn_point_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz,
+                              const float *new_xyz, int *idx, float *dist);
+
+/* Replaces PWCLO_utils.py:42-63 (warp): out = q (x) (0,xyz) (x) q^-1 + t, scalar-first
+ * quaternions, q^-1 = conj(q) / (|q|^2 + 1e-10).  xyz, out (b,3,n); q (b,4); t (b,3). */
+void quat_warp_kernel_wrapper(int b, int n, const float *xyz, const float *q, const float *t,
+                              float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWCLO_OPS_H */

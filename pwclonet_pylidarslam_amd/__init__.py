@@ -1,0 +1,1 @@
+"""MI355X-native PWCLO-Net point-cloud operator path."""

@@ -1,0 +1,75 @@
+"""ctypes binding of libpwclo_hip.so (the C ABI declared in include/pwclo_ops.h).
+
+There is deliberately no CPU or pure-PyTorch fallback: if the library is missing or a launch
+fails, the call raises.  ``load()`` never builds anything; run
+``python -m pwclonet_pylidarslam_amd.build`` (or ``__graft_entry__.build()``) first.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpwclo_hip.so")
+
+_F = ctypes.c_void_p  # device pointers travel as integers
+_i = ctypes.c_int
+
+# name -> argtypes, exactly the prototypes of include/pwclo_ops.h
+SIGNATURES = {
+    "pwclo_abi_version": ([], _i),
+    "pwclo_set_stream": ([ctypes.c_void_p], None),
+    "pwclo_get_stream": ([], ctypes.c_void_p),
+    "pwclo_last_error": ([], _i),
+    "pwclo_last_error_message": ([], ctypes.c_char_p),
+    "pwclo_clear_error": ([], None),
+    "gather_points_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F], None),
+    "gather_points_grad_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F], None),
+    "furthest_point_sampling_kernel_wrapper": ([_i, _i, _i, _F, _F, _F], None),
+    "group_points_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, _F, _F], None),
+    "group_points_grad_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, _F, _F], None),
+    "query_ball_point_kernel_wrapper": ([_i, _i, _i, ctypes.c_float, _i, _F, _F, _F], None),
+    "three_nn_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F], None),
+    "three_interpolate_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
+    "three_interpolate_grad_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
+    "knn_point_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
+    "quat_warp_kernel_wrapper": ([_i, _i, _F, _F, _F, _F], None),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libpwclo_hip.so is not built (%s missing). Build it with "
+                "`python -m pwclonet_pylidarslam_amd.build`; there is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header and library out of sync
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = lib
+    return _lib
+
+
+def check(what):
+    """Raise if the previous launch recorded an error (the reference would exit(-1))."""
+    lib = _lib
+    code = lib.pwclo_last_error()
+    if code != 0:
+        msg = lib.pwclo_last_error_message().decode("utf-8", "replace")
+        lib.pwclo_clear_error()
+        raise RuntimeError("%s failed (error %d): %s" % (what, code, msg))
+
+
+def call(name, device, *args):
+    """Launch `name` on torch's current stream of `device` and check the sticky error."""
+    lib = load()
+    with torch.cuda.device(device):
+        lib.pwclo_set_stream(ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+        getattr(lib, name)(*args)
+    check(name)

@@ -1,0 +1,72 @@
+"""Builds libpwclo_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m pwclonet_pylidarslam_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
+``pwclonet_pylidarslam_amd/lib/libpwclo_hip.so`` travels to the GPU box with the tree (it is
+git-ignored, not gpurun-ignored).  ``-ffp-contract=off``: the parity contract is source-order
+IEEE fp32 for every distance / interpolation expression (SURVEY.md section 7 "Hard parts").
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(HERE, "lib", "libpwclo_hip.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build libpwclo_hip.so")
+    return exe
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _newest_header_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "pwclo_ops.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+        os.path.getmtime(src), _newest_header_mtime())
+    if stale:
+        cmd = [hipcc()] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj, stale
+
+
+def build(force=False, jobs=None):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sources()
+    jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
+    with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in results]
+    if force or any(st for _, st in results) or not os.path.exists(LIB):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

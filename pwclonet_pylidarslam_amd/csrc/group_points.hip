@@ -1,0 +1,94 @@
+// group_points (+grad) for gfx950.  Replaces P2/_ext-src/src/group_points_gpu.cu.
+//
+// HBM-bound copy: out[b,c,j,k] = points[b,c,idx[b,j,k]].  The reference launches ONE block per
+// cloud and lets each thread write `nsample` consecutive floats (strided across the wave).  Here
+// the flattened (j,k) axis is spread over the grid: one thread owns 4 consecutive output
+// elements, loads their 4 indices with one 16-byte load (read once, reused for every channel of
+// the block's channel slice), gathers from the channel row (C*N*4 bytes per cloud: L2 resident)
+// and stores 16 bytes, so every wave-store is one contiguous 1 KiB line run.
+// Algorithmic bytes per call: 4*(S*K + C*N + C*S*K).
+#include "common.hpp"
+
+namespace pwclo {
+
+constexpr int GP_THREADS = 256;
+constexpr int GP_CH_PER_BLOCK = 8;  // channels handled by one block (grid.y = ceil(C / 8))
+
+// P = npoints*nsample.  VEC4 requires P % 4 == 0 (then every row start stays 16-byte aligned).
+template <bool VEC4>
+__global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, int P,
+                                                                  const float *__restrict__ points,
+                                                                  const int *__restrict__ idx,
+                                                                  float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * GP_CH_PER_BLOCK;
+  const int c1 = min(c0 + GP_CH_PER_BLOCK, c);
+  const int *ib = idx + (size_t)b * P;
+  if (VEC4) {
+    const int p = (blockIdx.x * GP_THREADS + threadIdx.x) * 4;
+    if (p >= P) return;
+    const int4 ii = *reinterpret_cast<const int4 *>(ib + p);
+    for (int l = c0; l < c1; ++l) {
+      const float *row = points + ((size_t)b * c + l) * n;
+      float4 v;
+      v.x = row[ii.x]; v.y = row[ii.y]; v.z = row[ii.z]; v.w = row[ii.w];
+      *reinterpret_cast<float4 *>(out + ((size_t)b * c + l) * P + p) = v;
+    }
+  } else {
+    const int p = blockIdx.x * GP_THREADS + threadIdx.x;
+    if (p >= P) return;
+    const int ii = ib[p];
+    for (int l = c0; l < c1; ++l)
+      out[((size_t)b * c + l) * P + p] = points[((size_t)b * c + l) * n + ii];
+  }
+}
+
+// grad_points[b,c,idx[b,p]] += grad_out[b,c,p]  (fp32 atomics into a zero-filled buffer).
+__global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(
+    int c, int n, int P, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    float *__restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * GP_CH_PER_BLOCK;
+  const int c1 = min(c0 + GP_CH_PER_BLOCK, c);
+  const int p = blockIdx.x * GP_THREADS + threadIdx.x;
+  if (p >= P) return;
+  const int ii = idx[(size_t)b * P + p];
+  for (int l = c0; l < c1; ++l)
+    atomicAdd(grad_points + ((size_t)b * c + l) * n + ii, grad_out[((size_t)b * c + l) * P + p]);
+}
+
+}  // namespace pwclo
+
+using namespace pwclo;
+
+extern "C" void group_points_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                            const float *points, const int *idx, float *out) {
+  if (b <= 0 || c <= 0 || npoints <= 0 || nsample <= 0) return;
+  const long long P64 = (long long)npoints * nsample;
+  PWCLO_REQUIRE(P64 < (1ll << 31) && b <= 65535, "group_points: npoints*nsample=%lld or b=%d too large",
+                P64, b);
+  const int P = (int)P64;
+  const int gy = ceil_div(c, GP_CH_PER_BLOCK);
+  const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(idx) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(group_points_kernel<true>, dim3(ceil_div(P / 4, GP_THREADS), gy, b),
+                       dim3(GP_THREADS), 0, current_stream(), c, n, P, points, idx, out);
+  else
+    hipLaunchKernelGGL(group_points_kernel<false>, dim3(ceil_div(P, GP_THREADS), gy, b),
+                       dim3(GP_THREADS), 0, current_stream(), c, n, P, points, idx, out);
+  check_launch("group_points");
+}
+
+extern "C" void group_points_grad_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                                 const float *grad_out, const int *idx,
+                                                 float *grad_points) {
+  if (b <= 0 || c <= 0 || npoints <= 0 || nsample <= 0) return;
+  const long long P64 = (long long)npoints * nsample;
+  PWCLO_REQUIRE(P64 < (1ll << 31) && b <= 65535,
+                "group_points_grad: npoints*nsample=%lld or b=%d too large", P64, b);
+  const int P = (int)P64;
+  hipLaunchKernelGGL(group_points_grad_kernel, dim3(ceil_div(P, GP_THREADS), ceil_div(c, GP_CH_PER_BLOCK), b),
+                     dim3(GP_THREADS), 0, current_stream(), c, n, P, grad_out, idx, grad_points);
+  check_launch("group_points_grad");
+}

@@ -1,0 +1,273 @@
+// Furthest point sampling + gather_points(+grad) for gfx950.
+//
+// Replaces P2/_ext-src/src/sampling_gpu.cu (reference).  Not a translation: the reference keeps
+// the running distances in global memory, re-reads every point each iteration and reduces
+// through a 9-level LDS tree with 10 barriers per iteration.  Here one workgroup owns one
+// cloud, every point and its running distance live in VGPRs for the whole call, the
+// per-iteration arg-max is a wave64 shuffle reduction followed by ONE barrier (double-buffered
+// LDS slots), and the winner's coordinates come from an LDS-resident copy of the cloud, so the
+// loop touches HBM only to store one index.
+//
+// FPS tie rule (must match the reference bit for bit): the reference runs
+// bs = opt_n_threads(n) threads; thread t = k mod bs keeps the FIRST maximum of its strided
+// points (strict >), then a tree that keeps slot t over slot t+s on ties.  Net effect: among
+// equal maxima the winner minimises (bitrev_{log2 bs}(k mod bs), k div bs) lexicographically.
+// That pair is packed into a 32-bit priority `pri = bitrev << 23 | (k div bs)`; the kernel
+// maximises the distance and, among equal distances, minimises pri.  A thread whose points are
+// all skipped (|p|^2 <= 1e-3) or out of range contributes nothing; if no thread has a
+// candidate the result is index 0, as in the reference (best = -1, besti = 0 everywhere).
+#include "common.hpp"
+
+namespace pwclo {
+
+constexpr int PRI_SHIFT = 23;  // k div bs < 2^23
+constexpr int FPS_SLOT_BYTES = 256;  // 2 x 16 u64 wave slots in front of the LDS point table
+
+__device__ __forceinline__ unsigned fps_bitrev(unsigned v, int bits) {
+  return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
+}
+
+// T threads, PPT points per thread (point k = tid + T*j).  T is a multiple of bs, so all points
+// of a thread share k mod bs and their priorities grow with j: a strict > in j order keeps the
+// thread's best-priority maximum, exactly like the reference thread does.
+template <int T, int PPT, bool LDS_TABLE>
+__global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int log2bs,
+                                                    const float *__restrict__ dataset,
+                                                    int *__restrict__ idxs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [2][16]
+  float4 *table = reinterpret_cast<float4 *>(smem + FPS_SLOT_BYTES);         // [n] when LDS_TABLE
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  constexpr int NW = T / 64;
+  const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+  int *out = idxs + (size_t)blockIdx.x * m;
+
+  float x[PPT], y[PPT], z[PPT], td[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int k = tid + T * j;
+    float px = 0.f, py = 0.f, pz = 0.f, t0 = -1.0f;  // -1: never a candidate
+    if (k < n) {
+      px = pts[k * 3 + 0];
+      py = pts[k * 3 + 1];
+      pz = pts[k * 3 + 2];
+      const float mag = (px * px) + (py * py) + (pz * pz);
+      if (!((double)mag <= 1e-3)) t0 = 1e10f;  // sampling.cpp:74-76 initial temp
+      if (LDS_TABLE) table[k] = make_float4(px, py, pz, 0.f);
+    }
+    x[j] = px; y[j] = py; z[j] = pz; td[j] = t0;
+  }
+  const int tpb = T / bs;  // priority step between consecutive points of one thread
+  const unsigned pri_base = (fps_bitrev((unsigned)(tid & (bs - 1)), log2bs) << PRI_SHIFT) |
+                            (unsigned)(tid / bs);
+  if (tid == 0) out[0] = 0;
+  __syncthreads();
+
+  int old = 0;
+  for (int it = 1; it < m; ++it) {
+    float x1, y1, z1;
+    if (LDS_TABLE) {
+      const float4 p = table[old];
+      x1 = p.x; y1 = p.y; z1 = p.z;
+    } else {
+      x1 = pts[old * 3 + 0]; y1 = pts[old * 3 + 1]; z1 = pts[old * 3 + 2];
+    }
+    float best = -1.0f;
+    int bestj = 0;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const float dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1;
+      const float d = dx * dx + dy * dy + dz * dz;  // -ffp-contract=off: (a+b)+c, no FMA
+      const float d2 = fminf(d, td[j]);
+      td[j] = d2;
+      const bool better = d2 > best;
+      bestj = better ? j : bestj;
+      best = better ? d2 : best;
+    }
+    // wave arg-max: max distance, then min priority among the lanes holding that distance
+    const float wmax = wave_allreduce_f32(best, [](float a, float b) { return fmaxf(a, b); });
+    unsigned pri = (best == wmax && best >= 0.0f) ? pri_base + (unsigned)(bestj * tpb) : 0xFFFFFFFFu;
+    pri = wave_allreduce_u32(pri, [](unsigned a, unsigned b) { return a < b ? a : b; });
+    unsigned long long key = 0ull;  // 0 = "no candidate in this wave"
+    if (wmax >= 0.0f)
+      key = ((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned long long)(0xFFFFFFFFu - pri);
+    if (NW > 1) {
+      unsigned long long *slot = slots + (it & 1) * 16;
+      if (lane == 0) slot[wave] = key;
+      __syncthreads();
+      unsigned long long kmax = slot[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const unsigned long long o = slot[w];
+        kmax = o > kmax ? o : kmax;
+      }
+      key = kmax;
+    }
+    if (key == 0ull) {
+      old = 0;
+    } else {
+      const unsigned p = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+      old = (int)fps_bitrev(p >> PRI_SHIFT, log2bs) + bs * (int)(p & ((1u << PRI_SHIFT) - 1u));
+    }
+    if (tid == 0) out[it] = old;
+  }
+}
+
+// Fallback for clouds too large for the register file: same selection rule, running distances in
+// the caller's temp buffer (pre-filled with 1e10), points re-read from global memory (L2).
+template <int T>
+__global__ __launch_bounds__(T) void fps_stream_kernel(int n, int m, int bs, int log2bs,
+                                                       const float *__restrict__ dataset,
+                                                       float *__restrict__ temp,
+                                                       int *__restrict__ idxs) {
+  __shared__ unsigned long long slots[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = T / 64;
+  const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+  float *tmp = temp + (size_t)blockIdx.x * n;
+  int *out = idxs + (size_t)blockIdx.x * m;
+  const unsigned rev = fps_bitrev((unsigned)(tid & (bs - 1)), log2bs) << PRI_SHIFT;
+  if (tid == 0) out[0] = 0;
+  int old = 0;
+  for (int it = 1; it < m; ++it) {
+    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+    float best = -1.0f;
+    unsigned bestpri = 0xFFFFFFFFu;
+    for (int k = tid; k < n; k += T) {
+      const float px = pts[k * 3 + 0], py = pts[k * 3 + 1], pz = pts[k * 3 + 2];
+      const float mag = (px * px) + (py * py) + (pz * pz);
+      if ((double)mag <= 1e-3) continue;
+      const float dx = px - x1, dy = py - y1, dz = pz - z1;
+      const float d = dx * dx + dy * dy + dz * dz;
+      const float d2 = fminf(d, tmp[k]);
+      tmp[k] = d2;
+      if (d2 > best) {  // k ascending within a thread => priorities ascending
+        best = d2;
+        bestpri = rev | (unsigned)(k >> log2bs);
+      }
+    }
+    const float wmax = wave_allreduce_f32(best, [](float a, float b) { return fmaxf(a, b); });
+    unsigned pri = (best == wmax && best >= 0.0f) ? bestpri : 0xFFFFFFFFu;
+    pri = wave_allreduce_u32(pri, [](unsigned a, unsigned b) { return a < b ? a : b; });
+    unsigned long long key = 0ull;
+    if (wmax >= 0.0f)
+      key = ((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned long long)(0xFFFFFFFFu - pri);
+    if (lane == 0) slots[it & 1][wave] = key;
+    __syncthreads();
+    unsigned long long kmax = slots[it & 1][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const unsigned long long o = slots[it & 1][w];
+      kmax = o > kmax ? o : kmax;
+    }
+    if (kmax == 0ull) {
+      old = 0;
+    } else {
+      const unsigned p = 0xFFFFFFFFu - (unsigned)(kmax & 0xFFFFFFFFull);
+      old = (int)fps_bitrev(p >> PRI_SHIFT, log2bs) + bs * (int)(p & ((1u << PRI_SHIFT) - 1u));
+    }
+    if (tid == 0) out[it] = old;
+  }
+}
+
+template <int T, int PPT>
+static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float *dataset, int *idxs) {
+  const size_t table_bytes = FPS_SLOT_BYTES + (size_t)n * sizeof(float4);
+  hipStream_t st = current_stream();
+  if (table_bytes <= 160 * 1024) {
+    auto kern = fps_reg_kernel<T, PPT, true>;
+    static bool big_lds_enabled = false;  // per instantiation; raises the 64 KiB dynamic-LDS default
+    if (table_bytes > 64 * 1024 && !big_lds_enabled) {
+      (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      big_lds_enabled = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(b), dim3(T), table_bytes, st, n, m, bs, log2bs, dataset, idxs);
+  } else {
+    hipLaunchKernelGGL((fps_reg_kernel<T, PPT, false>), dim3(b), dim3(T), FPS_SLOT_BYTES, st, n, m,
+                       bs, log2bs, dataset, idxs);
+  }
+}
+
+// out[b,c,j] = points[b,c,idx[b,j]]; grid (ceil(m/256), c, b) so that small m still fills CUs.
+__global__ __launch_bounds__(256) void gather_points_kernel(int c, int n, int m,
+                                                            const float *__restrict__ points,
+                                                            const int *__restrict__ idx,
+                                                            float *__restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const size_t row = (size_t)blockIdx.z * c + blockIdx.y;
+  const int a = idx[(size_t)blockIdx.z * m + j];
+  out[row * m + j] = points[row * n + a];
+}
+
+__global__ __launch_bounds__(256) void gather_points_grad_kernel(int c, int n, int m,
+                                                                 const float *__restrict__ grad_out,
+                                                                 const int *__restrict__ idx,
+                                                                 float *__restrict__ grad_points) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const size_t row = (size_t)blockIdx.z * c + blockIdx.y;
+  const int a = idx[(size_t)blockIdx.z * m + j];
+  atomicAdd(grad_points + row * n + a, grad_out[row * m + j]);
+}
+
+}  // namespace pwclo
+
+using namespace pwclo;
+
+extern "C" void furthest_point_sampling_kernel_wrapper(int b, int n, int m, const float *dataset,
+                                                       float *temp, int *idxs) {
+  if (b <= 0 || m <= 0) return;
+  PWCLO_REQUIRE(n >= 1, "furthest_point_sampling: n=%d must be >= 1", n);
+  PWCLO_REQUIRE((long long)n < (1ll << PRI_SHIFT) * 1ll, "furthest_point_sampling: n=%d too large", n);
+  const int bs = ref_opt_n_threads(n);
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  // Thread count: a multiple of bs (see kernel comment); 1024 threads once a cloud has more than
+  // 4096 points so that at most 16 points sit in one thread's registers up to n = 16384.
+  int T = bs < 64 ? 64 : bs;
+  if (n > 4096) T = 1024;
+  int ppt = ceil_div(n, T);
+  if (n > 16384 && n <= 24576) { T = 512; ppt = ceil_div(n, T); }
+#define FPS_CASE(TT, PP)                                                   \
+  if (T == TT && ppt <= PP) {                                              \
+    launch_fps_reg<TT, PP>(b, n, m, bs, log2bs, dataset, idxs);           \
+    check_launch("furthest_point_sampling");                              \
+    return;                                                                \
+  }
+  FPS_CASE(64, 1) FPS_CASE(64, 2)
+  FPS_CASE(128, 1) FPS_CASE(128, 2)
+  FPS_CASE(256, 1) FPS_CASE(256, 2)
+  FPS_CASE(512, 1) FPS_CASE(512, 2) FPS_CASE(512, 4) FPS_CASE(512, 8)
+  FPS_CASE(1024, 8) FPS_CASE(1024, 16)
+  FPS_CASE(512, 48)
+#undef FPS_CASE
+  PWCLO_REQUIRE(temp != nullptr,
+                "furthest_point_sampling: n=%d needs the (b,n) temp buffer pre-filled with 1e10", n);
+  hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, current_stream(), n, m, bs,
+                     log2bs, dataset, temp, idxs);
+  check_launch("furthest_point_sampling(stream)");
+}
+
+extern "C" void gather_points_kernel_wrapper(int b, int c, int n, int npoints, const float *points,
+                                             const int *idx, float *out) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return;
+  PWCLO_REQUIRE(c <= 65535 && b <= 65535, "gather_points: b=%d c=%d exceed the grid limits", b, c);
+  hipLaunchKernelGGL(gather_points_kernel, dim3(ceil_div(npoints, 256), c, b), dim3(256), 0,
+                     current_stream(), c, n, npoints, points, idx, out);
+  check_launch("gather_points");
+}
+
+extern "C" void gather_points_grad_kernel_wrapper(int b, int c, int n, int npoints,
+                                                  const float *grad_out, const int *idx,
+                                                  float *grad_points) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return;
+  PWCLO_REQUIRE(c <= 65535 && b <= 65535, "gather_points_grad: b=%d c=%d exceed the grid limits", b, c);
+  hipLaunchKernelGGL(gather_points_grad_kernel, dim3(ceil_div(npoints, 256), c, b), dim3(256), 0,
+                     current_stream(), c, n, npoints, grad_out, idx, grad_points);
+  check_launch("gather_points_grad");
+}

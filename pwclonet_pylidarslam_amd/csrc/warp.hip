@@ -1,0 +1,54 @@
+// Quaternion pose warp for gfx950.  Replaces PW/PWCLO_utils.py:31-63 (warp = two Hamilton
+// products built from ~40 tiny torch ops, plus two host-side tensor constructions and H2D copies
+// per call).  One thread per point, streaming (B,3,N) -> (B,3,N); the products follow the
+// reference's term order (PWCLO_utils.py:83-95,117-129) without contraction so the warped
+// coordinates -- which feed the neighbour searches of the refinement levels -- agree with the
+// reference to the last bit wherever torch's own evaluation order is defined.
+#include "common.hpp"
+
+namespace pwclo {
+
+struct quat { float w, x, y, z; };
+
+// Hamilton product a (x) b with the reference's left-to-right evaluation of each component.
+__device__ __forceinline__ quat hamilton(const quat a, const quat b) {
+  quat r;
+  r.w = ((a.w * b.w - a.x * b.x) - a.y * b.y) - a.z * b.z;
+  r.x = ((a.w * b.x + a.x * b.w) + a.y * b.z) - a.z * b.y;
+  r.y = ((a.w * b.y - a.x * b.z) + a.y * b.w) + a.z * b.x;
+  r.z = ((a.w * b.z + a.x * b.y) - a.y * b.x) + a.z * b.w;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void quat_warp_kernel(int n, const float *__restrict__ xyz,
+                                                        const float *__restrict__ q,
+                                                        const float *__restrict__ t,
+                                                        float *__restrict__ out) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const quat qq = {q[b * 4 + 0], q[b * 4 + 1], q[b * 4 + 2], q[b * 4 + 3]};
+  // inv_q (PWCLO_utils.py:31-39): conj(q) / (sum(q*q) + 1e-10)
+  const float q2 = (((qq.w * qq.w + qq.x * qq.x) + qq.y * qq.y) + qq.z * qq.z) + 1e-10f;
+  const quat qi = {qq.w / q2, (qq.x * -1.0f) / q2, (qq.y * -1.0f) / q2, (qq.z * -1.0f) / q2};
+  const float *src = xyz + (size_t)b * 3 * n;
+  const quat p = {0.0f, src[j], src[n + j], src[2 * n + j]};
+  const quat r = hamilton(hamilton(qq, p), qi);
+  float *dst = out + (size_t)b * 3 * n;
+  dst[j] = r.x + t[b * 3 + 0];
+  dst[n + j] = r.y + t[b * 3 + 1];
+  dst[2 * n + j] = r.z + t[b * 3 + 2];
+}
+
+}  // namespace pwclo
+
+using namespace pwclo;
+
+extern "C" void quat_warp_kernel_wrapper(int b, int n, const float *xyz, const float *q,
+                                         const float *t, float *out) {
+  if (b <= 0 || n <= 0) return;
+  PWCLO_REQUIRE(b <= 65535, "quat_warp: b=%d exceeds the grid limit", b);
+  hipLaunchKernelGGL(quat_warp_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, current_stream(), n,
+                     xyz, q, t, out);
+  check_launch("quat_warp");
+}

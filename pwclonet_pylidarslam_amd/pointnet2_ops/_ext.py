@@ -1,0 +1,166 @@
+"""The ``pointnet2_ops._ext`` function surface on top of libpwclo_hip.so.
+
+Mirrors the reference's pybind module (``P2/_ext-src/src/bindings.cpp:6-19``): same nine names,
+argument order and return values, and the host-side conventions of its ``.cpp`` files --
+dtype / contiguity checks that raise ``RuntimeError`` (``utils.h:5-25``), zero-initialised
+outputs on the inputs' device (relied on by the grad kernels and by ball_query's "no hit"
+case), "CPU not supported" for host tensors.  Two extra entry points cover the pure-PyTorch
+ops of the same path that get native kernels here: ``knn_point`` and ``quat_warp``.
+
+Unlike the reference there is no JIT fallback and no silent path: every function launches a
+HIP kernel through the C ABI or raises.
+"""
+import torch
+
+from .. import _lib
+
+
+def _chk(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _float(t, name):
+    _chk(t.is_contiguous(), name + " must be a contiguous tensor")
+    _chk(t.dtype == torch.float32, name + " must be a float tensor")
+
+
+def _int(t, name):
+    _chk(t.is_contiguous(), name + " must be a contiguous tensor")
+    _chk(t.dtype == torch.int32, name + " must be an int tensor")
+
+
+def _gpu(t, *others):
+    _chk(t.is_cuda, "CPU not supported")
+    for o in others:
+        _chk(o.is_cuda and o.device == t.device, "all tensors must be on the same CUDA/HIP device")
+
+
+def _p(t):
+    return t.data_ptr()
+
+
+def gather_points(points, idx):
+    """sampling.cpp:15-38.  (B,C,N) f32, (B,M) i32 -> (B,C,M) f32."""
+    _float(points, "points"); _int(idx, "idx"); _gpu(points, idx)
+    B, C, N = points.shape
+    M = idx.shape[1]
+    out = torch.zeros((B, C, M), dtype=torch.float32, device=points.device)
+    _lib.call("gather_points_kernel_wrapper", points.device, B, C, N, M, _p(points), _p(idx), _p(out))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """sampling.cpp:40-65.  (B,C,M), (B,M), n -> (B,C,n)."""
+    _float(grad_out, "grad_out"); _int(idx, "idx"); _gpu(grad_out, idx)
+    B, C, M = grad_out.shape
+    out = torch.zeros((B, C, n), dtype=torch.float32, device=grad_out.device)
+    _lib.call("gather_points_grad_kernel_wrapper", grad_out.device, B, C, n, M, _p(grad_out), _p(idx),
+              _p(out))
+    return out
+
+
+def furthest_point_sampling(points, nsamples):
+    """sampling.cpp:66-87.  (B,N,3) f32 -> (B,nsamples) i32.  The reference's (B,N) `tmp` scratch
+    is only allocated when the cloud is too large for the register-resident kernel."""
+    _float(points, "points"); _gpu(points)
+    B, N, _ = points.shape
+    out = torch.zeros((B, nsamples), dtype=torch.int32, device=points.device)
+    tmp = 0
+    if N > 24576:
+        tmp_t = torch.full((B, N), 1e10, dtype=torch.float32, device=points.device)
+        tmp = _p(tmp_t)
+    _lib.call("furthest_point_sampling_kernel_wrapper", points.device, B, N, nsamples, _p(points), tmp,
+              _p(out))
+    return out
+
+
+def three_nn(unknowns, knows):
+    """interpolate.cpp:14-40.  Returns [dist2 (B,n,3) f32, idx (B,n,3) i32]."""
+    _float(unknowns, "unknowns"); _float(knows, "knows"); _gpu(unknowns, knows)
+    B, n, _ = unknowns.shape
+    m = knows.shape[1]
+    idx = torch.zeros((B, n, 3), dtype=torch.int32, device=unknowns.device)
+    dist2 = torch.zeros((B, n, 3), dtype=torch.float32, device=unknowns.device)
+    _lib.call("three_nn_kernel_wrapper", unknowns.device, B, n, m, _p(unknowns), _p(knows), _p(dist2),
+              _p(idx))
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """interpolate.cpp:42-70.  (B,c,m), (B,n,3) i32, (B,n,3) f32 -> (B,c,n)."""
+    _float(points, "points"); _int(idx, "idx"); _float(weight, "weight"); _gpu(points, idx, weight)
+    B, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.zeros((B, c, n), dtype=torch.float32, device=points.device)
+    _lib.call("three_interpolate_kernel_wrapper", points.device, B, c, m, n, _p(points), _p(idx),
+              _p(weight), _p(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """interpolate.cpp:71-99.  (B,c,n), idx, weight, m -> (B,c,m)."""
+    _float(grad_out, "grad_out"); _int(idx, "idx"); _float(weight, "weight")
+    _gpu(grad_out, idx, weight)
+    B, c, n = grad_out.shape
+    out = torch.zeros((B, c, m), dtype=torch.float32, device=grad_out.device)
+    _lib.call("three_interpolate_grad_kernel_wrapper", grad_out.device, B, c, n, m, _p(grad_out),
+              _p(idx), _p(weight), _p(out))
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """ball_query.cpp:8-32.  NOTE the (new_xyz, xyz) order.  -> (B,M,nsample) i32."""
+    _float(new_xyz, "new_xyz"); _float(xyz, "xyz"); _gpu(new_xyz, xyz)
+    B, M, _ = new_xyz.shape
+    N = xyz.shape[1]
+    idx = torch.zeros((B, M, nsample), dtype=torch.int32, device=new_xyz.device)
+    _lib.call("query_ball_point_kernel_wrapper", new_xyz.device, B, N, M, float(radius), int(nsample),
+              _p(new_xyz), _p(xyz), _p(idx))
+    return idx
+
+
+def group_points(points, idx):
+    """group_points.cpp:12-36.  (B,C,N) f32, (B,S,K) i32 -> (B,C,S,K)."""
+    _float(points, "points"); _int(idx, "idx"); _gpu(points, idx)
+    B, C, N = points.shape
+    S, K = idx.shape[1], idx.shape[2]
+    out = torch.empty((B, C, S, K), dtype=torch.float32, device=points.device)  # fully overwritten
+    _lib.call("group_points_kernel_wrapper", points.device, B, C, N, S, K, _p(points), _p(idx), _p(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """group_points.cpp:38-62.  (B,C,S,K), (B,S,K), n -> (B,C,n)."""
+    _float(grad_out, "grad_out"); _int(idx, "idx"); _gpu(grad_out, idx)
+    B, C, S, K = grad_out.shape
+    out = torch.zeros((B, C, n), dtype=torch.float32, device=grad_out.device)
+    _lib.call("group_points_grad_kernel_wrapper", grad_out.device, B, C, n, S, K, _p(grad_out), _p(idx),
+              _p(out))
+    return out
+
+
+# ---- native replacements of pure-PyTorch ops (include/pwclo_ops.h section 2) ---------------------
+
+def knn_point(nsample, xyz, new_xyz, return_dist=False):
+    """Native kernel behind ``pytorch_utils.knn_point``.  xyz (B,N,3), new_xyz (B,S,3) ->
+    idx (B,S,nsample) i32 ascending by distance (ties: lower index); optionally the keys."""
+    _float(xyz, "xyz"); _float(new_xyz, "new_xyz"); _gpu(xyz, new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
+    dist = torch.empty((B, S, nsample), dtype=torch.float32, device=xyz.device) if return_dist else None
+    _lib.call("knn_point_kernel_wrapper", xyz.device, B, N, S, int(nsample), _p(xyz), _p(new_xyz), _p(idx),
+              _p(dist) if return_dist else 0)
+    return (dist, idx) if return_dist else idx
+
+
+def quat_warp(xyz, q, t):
+    """Native kernel behind ``PWCLO_utils.warp``.  xyz (B,3,N), q (B,4[,1]), t (B,3[,1])."""
+    B, _, N = xyz.shape
+    q = q.reshape(B, 4).contiguous()
+    t = t.reshape(B, 3).contiguous()
+    _float(xyz, "xyz"); _float(q, "q"); _float(t, "t"); _gpu(xyz, q, t)
+    out = torch.empty_like(xyz)
+    _lib.call("quat_warp_kernel_wrapper", xyz.device, B, N, _p(xyz), _p(q), _p(t), _p(out))
+    return out

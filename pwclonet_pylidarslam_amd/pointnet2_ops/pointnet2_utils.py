@@ -1,0 +1,153 @@
+"""``torch.autograd.Function`` wrappers with the reference's names and signatures
+(``P2/pointnet2_utils.py:34-276``) over the HIP extension surface in ``._ext``.
+
+Differentiability matches the reference: FPS / three_nn / ball_query outputs are marked
+non-differentiable and their backward returns ``()``; gather / group / three_interpolate send
+the gradient to ``features`` only (``grad_out.contiguous()`` first, :97,185,235).
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _ext
+
+
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        """xyz (B,N,3) -> (B,npoint) int32 indices (pointnet2_utils.py:36-59)."""
+        out = _ext.furthest_point_sampling(xyz, npoint)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ()
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        """features (B,C,N), idx (B,npoint) -> (B,C,npoint) (pointnet2_utils.py:70-91)."""
+        ctx.save_for_backward(idx)
+        ctx.n = features.size(2)
+        return _ext.gather_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _ext.gather_points_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown, known):
+        """-> (dist (B,n,3) = sqrt(dist2), idx (B,n,3)) (pointnet2_utils.py:106-129)."""
+        dist2, idx = _ext.three_nn(unknown, known)
+        dist = torch.sqrt(dist2)
+        ctx.mark_non_differentiable(dist, idx)
+        return dist, idx
+
+    @staticmethod
+    def backward(ctx, grad_dist, grad_idx):
+        return ()
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        """features (B,c,m), idx/weight (B,n,3) -> (B,c,n) (pointnet2_utils.py:141-161)."""
+        ctx.save_for_backward(idx, weight)
+        ctx.m = features.size(2)
+        return _ext.three_interpolate(features, idx, weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        grad_features = _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m)
+        return grad_features, torch.zeros_like(idx), torch.zeros_like(weight)
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)
+        (pointnet2_utils.py:196-214)."""
+        ctx.save_for_backward(idx)
+        ctx.n = features.size(2)
+        return _ext.group_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n), torch.zeros_like(idx)
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz):
+        """(radius, nsample, xyz (B,N,3), new_xyz (B,npoint,3)) -> (B,npoint,nsample) int32.
+        The ext entry point takes (new_xyz, xyz, ...) -- pointnet2_utils.py:265."""
+        output = _ext.ball_query(new_xyz, xyz, radius, nsample)
+        ctx.mark_non_differentiable(output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ()
+
+
+ball_query = BallQuery.apply
+
+
+class QueryAndGroup(nn.Module):
+    """Ball-query grouper (pointnet2_utils.py:279-335): (xyz (B,N,3), new_xyz (B,npoint,3),
+    features (B,C,N) or None) -> (B, 3+C, npoint, nsample)."""
+
+    def __init__(self, radius, nsample, use_xyz=True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return grouped_xyz
+        grouped_features = grouping_operation(features, idx)
+        if self.use_xyz:
+            return torch.cat([grouped_xyz, grouped_features], dim=1)
+        return grouped_features
+
+
+class GroupAll(nn.Module):
+    """pointnet2_utils.py:419-464: one group holding every point -> (B, 3+C, 1, N)."""
+
+    def __init__(self, use_xyz=True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is None:
+            return grouped_xyz
+        grouped_features = features.unsqueeze(2)
+        if self.use_xyz:
+            return torch.cat([grouped_xyz, grouped_features], dim=1)
+        return grouped_features

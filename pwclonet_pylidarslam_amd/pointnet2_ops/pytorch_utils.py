@@ -1,0 +1,125 @@
+"""Host-side mirror of ``P2/pytorch_utils.py``: ``knn_point`` on the native kernel, and the
+Conv/BN/ReLU building blocks with the reference's ``state_dict`` naming
+(``<name>.layer{i}.conv.weight``, ``<name>.layer{i}.bn.bn.{weight,bias,running_mean,...}``).
+"""
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _ext
+
+
+def knn_point(nsample, xyz, new_xyz):
+    """(nsample, xyz (B,N,3), new_xyz (B,S,3)) -> (group_idx, group_idx) with group_idx
+    (B,S,nsample) int32, ascending distance.  The reference returns the index tensor in both
+    positions (pytorch_utils.py:46-49; every caller discards the first) and so does this.
+    Native HIP kernel instead of the dense (B,S,N) distance matrix + torch.topk."""
+    idx = _ext.knn_point(nsample, xyz.contiguous(), new_xyz.contiguous())
+    return idx, idx
+
+
+class _BN(nn.Sequential):
+    """pytorch_utils.py:86-111: a Sequential holding one BatchNorm under the name ``bn``
+    (weight 1, bias 0), so parameters appear as ``...bn.bn.weight``."""
+
+    def __init__(self, in_size, batch_norm):
+        super().__init__()
+        self.add_module("bn", batch_norm(in_size))
+        nn.init.constant_(self[0].weight, 1.0)
+        nn.init.constant_(self[0].bias, 0)
+
+
+class BatchNorm1d(_BN):
+    def __init__(self, in_size: int, *, name: str = ""):
+        super().__init__(in_size, nn.BatchNorm1d)
+
+
+class BatchNorm2d(_BN):
+    def __init__(self, in_size: int, name: str = ""):
+        super().__init__(in_size, nn.BatchNorm2d)
+
+
+class _ConvBlock(nn.Sequential):
+    """pytorch_utils.py:114-167: [bn, act,] conv [, bn, act]; the conv has a bias only when
+    there is no batch norm; modules are registered as ``conv`` / ``bn`` / ``activation``."""
+
+    def __init__(self, conv_cls, bn_cls, in_size, out_size, kernel_size, stride, padding, activation,
+                 bn, init, bias, preact):
+        super().__init__()
+        bias = bias and (not bn)
+        conv = conv_cls(in_size, out_size, kernel_size=kernel_size, stride=stride, padding=padding,
+                        bias=bias)
+        init(conv.weight)
+        if bias:
+            nn.init.constant_(conv.bias, 0)
+        if preact:
+            if bn:
+                self.add_module("bn", bn_cls(in_size))
+            if activation is not None:
+                self.add_module("activation", activation)
+        self.add_module("conv", conv)
+        if not preact:
+            if bn:
+                self.add_module("bn", bn_cls(out_size))
+            if activation is not None:
+                self.add_module("activation", activation)
+
+
+class Conv1d(_ConvBlock):
+    def __init__(self, in_size: int, out_size: int, *, kernel_size: int = 1, stride: int = 1,
+                 padding=0, activation=nn.ReLU(inplace=True), bn: bool = False,
+                 init=nn.init.kaiming_normal_, bias: bool = True, preact: bool = False, name: str = ""):
+        super().__init__(nn.Conv1d, BatchNorm1d, in_size, out_size, kernel_size, stride, padding,
+                         activation, bn, init, bias, preact)
+
+
+class Conv2d(_ConvBlock):
+    def __init__(self, in_size: int, out_size: int, *, kernel_size: Tuple[int, int] = (1, 1),
+                 stride: Tuple[int, int] = (1, 1), padding=(0, 0), activation=nn.ReLU(inplace=True),
+                 bn: bool = False, init=nn.init.kaiming_normal_, bias: bool = True,
+                 preact: bool = False, name: str = ""):
+        super().__init__(nn.Conv2d, BatchNorm2d, in_size, out_size, kernel_size, stride, padding,
+                         activation, bn, init, bias, preact)
+
+
+class SharedMLP(nn.Sequential):
+    """pytorch_utils.py:52-83: ``layer{i}`` = Conv2d(1x1) [+ BN] + ReLU over (B,C,S,K)."""
+
+    def __init__(self, args: List[int], *, bn: bool = False, activation=nn.ReLU(inplace=True),
+                 preact: bool = False, first: bool = False, name: str = "",
+                 init=nn.init.kaiming_normal_):
+        super().__init__()
+        for i in range(len(args) - 1):
+            plain = (not first) or (not preact) or (i != 0)
+            self.add_module(name + "layer{}".format(i),
+                            Conv2d(args[i], args[i + 1], bn=plain and bn,
+                                   activation=activation if plain else None, preact=preact, init=init))
+
+
+def set_bn_momentum_default(bn_momentum):
+    def fn(m):
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.momentum = bn_momentum
+    return fn
+
+
+class BNMomentumScheduler(object):
+    """pytorch_utils.py:319-349."""
+
+    def __init__(self, model, bn_lambda, last_epoch=-1, setter=set_bn_momentum_default):
+        if not isinstance(model, nn.Module):
+            raise RuntimeError("Class '{}' is not a PyTorch nn Module".format(type(model).__name__))
+        self.model = model
+        self.setter = setter
+        self.lmbd = bn_lambda
+        self.last_momentum = self.lmbd(0)
+        self.step(last_epoch + 1)
+        self.last_epoch = last_epoch
+
+    def step(self, epoch=None):
+        if epoch is None:
+            epoch = self.last_epoch + 1
+        self.last_epoch = epoch
+        self.last_momentum = self.lmbd(epoch)
+        self.model.apply(self.setter(self.lmbd(epoch)))

@@ -1,0 +1,61 @@
+"""Attentive cost volume (double attentive embedding), ``PW/costvolume.py:19-190``."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..pointnet2_ops import pointnet2_utils as pointutils
+from ..pointnet2_ops import pytorch_utils as pt_utils
+
+
+def _geometry(centre_xyz, grouped_xyz):
+    """10-channel geometry encoding [p, q, q-p, |q-p|] (costvolume.py:92-105); centre_xyz
+    (B,3,S), grouped_xyz (B,3,S,K) -> (B,10,S,K)."""
+    p = centre_xyz.unsqueeze(3).expand_as(grouped_xyz)
+    diff = grouped_xyz - p
+    euc = torch.sqrt(torch.sum(torch.square(diff), dim=1, keepdim=True) + 1e-20)
+    return torch.cat((p, grouped_xyz, diff, euc), dim=1)
+
+
+class CostVolume(nn.Module):
+    """(warped_xyz (B,3,S), warped_points (B,C1,S), f2_xyz (B,3,N), f2_points (B,C2,N))
+    -> (B, mlp2[-1], S).  Requires mlp1[-1] == mlp2[-1]."""
+
+    def __init__(self, nsample, nsample_q, in_channel1, in_channel2, mlp1, mlp2):
+        super().__init__()
+        self.nsample = nsample
+        self.nsample_q = nsample_q
+        self.in_channel = [in_channel1, in_channel2, 10]
+        xavier = torch.nn.init.xavier_uniform_
+        mlp1_spec = [in_channel1 + in_channel2 + 10] + mlp1
+        self.mlp_convs = pt_utils.SharedMLP(mlp1_spec, bn=True, init=xavier)
+        self.mlp_conv_xyz_1 = pt_utils.SharedMLP([10, mlp1[-1]], bn=True, init=xavier)
+        self.mlp_conv_xyz_2 = pt_utils.SharedMLP([10, mlp1[-1]], bn=True, init=xavier)
+        self.mlp2_convs = pt_utils.SharedMLP([mlp1_spec[-1] * 2] + mlp2, bn=True, init=xavier)
+        mlp3_spec = [mlp1_spec[-1] * 2 + in_channel1] + mlp2
+        self.mlp3_convs = pt_utils.SharedMLP(mlp3_spec, bn=True, init=xavier)
+        self.out_channel = mlp3_spec[-1]
+
+    def forward(self, warped_xyz, warped_points, f2_xyz, f2_points):
+        warped_xyz_t = warped_xyz.permute(0, 2, 1).contiguous()
+        f2_xyz_t = f2_xyz.permute(0, 2, 1).contiguous()
+        kq, k = self.nsample_q, self.nsample
+
+        # first aggregate: frame-2 neighbours of every (warped) frame-1 point
+        _, idx_q = pt_utils.knn_point(kq, f2_xyz_t, warped_xyz_t)
+        q_xyz = pointutils.grouping_operation(f2_xyz.contiguous(), idx_q)
+        q_pts = pointutils.grouping_operation(f2_points.contiguous(), idx_q)
+        geo = _geometry(warped_xyz, q_xyz)
+        p_pts = warped_points.unsqueeze(3).expand(-1, -1, -1, kq)
+        feat = self.mlp_convs(torch.cat((geo, p_pts, q_pts), dim=1))
+        enc = self.mlp_conv_xyz_1(geo)
+        w = F.softmax(self.mlp2_convs(torch.cat((enc, feat), dim=1)), dim=3)
+        first = torch.sum(w * feat, dim=3)
+
+        # second aggregate: frame-1 neighbours of every frame-1 point
+        _, idx = pt_utils.knn_point(k, warped_xyz_t, warped_xyz_t)
+        c_xyz = pointutils.grouping_operation(warped_xyz.contiguous(), idx)
+        c_pts = pointutils.grouping_operation(first.contiguous(), idx)
+        enc2 = self.mlp_conv_xyz_2(_geometry(warped_xyz, c_xyz))
+        p_pts2 = warped_points.unsqueeze(3).expand(-1, -1, -1, k)
+        w2 = F.softmax(self.mlp3_convs(torch.cat((enc2, p_pts2, c_pts), dim=1)), dim=3)
+        return torch.sum(w2 * c_pts, dim=3)

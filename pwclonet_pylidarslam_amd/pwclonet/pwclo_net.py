@@ -1,0 +1,113 @@
+"""PWCLO-Net (``PW/pwclo_net.py:32-207``) on the MI355X operator stack.
+
+Same constructor (``PWCLONet(config, pose)``), ``forward`` signature and ``state_dict`` keys as
+the reference, so a reference checkpoint loads unchanged.  Differences are only in how the
+work is scheduled:
+  * ``forward`` runs the reference-shaped graph on the HIP operators (any mode, autograd ok);
+  * ``log_dict`` is the reference's (host tensors, forces a D2H sync, pwclo_net.py:186-193) by
+    default; ``log_mode="device"`` keeps the same values on the GPU without a sync and
+    ``log_mode="none"`` skips them -- the benchmark states which one it used.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..pointnet2_ops.pointnet2_modules import PointnetSAModulePWCLONet
+from .costvolume import CostVolume
+from .flowpredictor import FlowPredictor
+from .pose_calculator import PoseCalculator
+from .pose_warp_refinement import PoseWarpRefinement
+
+
+def _cfg(config, key, default=None):
+    if hasattr(config, "get"):
+        v = config.get(key, default)
+        return default if v is None else v
+    return getattr(config, key, default)
+
+
+def _unit(q):
+    return q / (torch.sqrt(torch.sum(q * q, dim=-1, keepdim=True) + 1e-10) + 1e-10)
+
+
+class PWCLONet(nn.Module):
+    """(xyz_f1 (B,3,N), None, xyz_f2 (B,3,N), None) -> (pose_params (B,4,7), log_dict).
+    Rows of pose_params = pyramid levels 1 (finest) .. 4, each [tx,ty,tz,qw,qx,qy,qz]."""
+
+    def __init__(self, config, pose=None):
+        super().__init__()
+        self.config = config
+        self.pose = pose
+        self.num_out_poses = _cfg(config, "num_out_poses", 1)
+        self.num_input_channels = _cfg(config, "num_input_channels", 3)
+        self.sequence_len = _cfg(config, "sequence_len", 2)
+        self.device = torch.device(_cfg(config, "device", "cuda"))
+        self.nb_levels = _cfg(config, "num_out_poses", 4)
+        self.log_mode = _cfg(config, "log_mode", "host")
+        scalar_last = _cfg(config, "scalar_last", False)
+        dev = str(_cfg(config, "device", "cuda"))
+
+        # siamese point feature pyramid (pwclo_net.py:66-69)
+        self.psa_1 = PointnetSAModulePWCLONet(npoint=2048, nsample=32, mlp=[0, 8, 8, 16], bn=True)
+        self.psa_2 = PointnetSAModulePWCLONet(npoint=1024, nsample=32, mlp=[16, 16, 16, 32], bn=True)
+        self.psa_3 = PointnetSAModulePWCLONet(npoint=256, nsample=16, mlp=[32, 32, 32, 64], bn=True)
+        self.psa_4 = PointnetSAModulePWCLONet(npoint=64, nsample=16, mlp=[64, 64, 64, 128], bn=True)
+        # attentive cost volume at level 3 + flow feature encoding (:73-78)
+        self.cost_volume = CostVolume(nsample=4, nsample_q=32, in_channel1=64, in_channel2=64,
+                                      mlp1=[128, 64, 64], mlp2=[128, 64])
+        self.flow_feature_encoding = PointnetSAModulePWCLONet(npoint=64, nsample=16,
+                                                              mlp=[64, 128, 64, 64], bn=True)
+        # level-4 mask + pose head (:84-86)
+        self.l4_flow_predictor = FlowPredictor(in_channel=128 + 64, mlp=[128, 64])
+        self.pose_calculator_4 = PoseCalculator(in_channel=64, out_channel=256, kernel_size=1,
+                                                padding="valid", activation=None, squeeze=True)
+        # pose warp-refinement, levels 3..1 (:94-106)
+        common = dict(in_channel_f1_prev=64, in_channel_mask=64, device=dev, scalar_last=scalar_last)
+        self.pose_warp_refinement_3 = PoseWarpRefinement(in_channel_f1=64, in_channel_f2=64, radius=2.0,
+                                                         last_pose_estimation=False, **common)
+        self.pose_warp_refinement_2 = PoseWarpRefinement(in_channel_f1=32, in_channel_f2=32, radius=1.0,
+                                                         last_pose_estimation=False, **common)
+        self.pose_warp_refinement_1 = PoseWarpRefinement(in_channel_f1=16, in_channel_f2=16, radius=0.5,
+                                                         last_pose_estimation=True, **common)
+
+    def _pyramid(self, xyz_t, points):
+        levels = []
+        x, f = xyz_t, points
+        for sa in (self.psa_1, self.psa_2, self.psa_3, self.psa_4):
+            x, f = sa(x, f)
+            levels.append((x, f))
+        return levels
+
+    def forward(self, xyz_f1, points_f1, xyz_f2, points_f2, bn_decay=None):
+        cf = lambda z: z.permute(0, 2, 1).contiguous()
+        l1 = self._pyramid(cf(xyz_f1), points_f1)
+        l2 = self._pyramid(cf(xyz_f2), points_f2)
+        (x11t, p11), (x12t, p12), (x13t, p13), (_x14t, p14) = l1
+        (x21t, p21), (x22t, p22), (x23t, p23), _ = l2
+        x11, x12, x13 = cf(x11t), cf(x12t), cf(x13t)
+        x21, x22, x23 = cf(x21t), cf(x22t), cf(x23t)
+
+        flow_embedding = self.cost_volume(x13, p13, x23, p23)
+        x14t, emb4 = self.flow_feature_encoding(x13t, flow_embedding)
+        x14 = cf(x14t)
+
+        mask4 = self.l4_flow_predictor(p14, emb4)
+        q4, t4 = self.pose_calculator_4(emb4, F.softmax(mask4, dim=2))
+
+        q3, t3, emb3, mask3 = self.pose_warp_refinement_3(x13, p13, x23, p23, x14, emb4, mask4, q4, t4)
+        q2, t2, emb2, mask2 = self.pose_warp_refinement_2(x12, p12, x22, p22, x13, emb3, mask3, q3, t3)
+        q1, t1, _emb1, mask1 = self.pose_warp_refinement_1(x11, p11, x21, p21, x12, emb2, mask2, q2, t2)
+
+        log_dict = {}
+        if self.log_mode != "none":
+            m1 = mask1.detach()
+            pc = x11t.detach()
+            if self.log_mode == "host":  # reference behaviour: D2H before the softmax
+                m1, pc = m1.cpu(), pc.cpu()
+            log_dict = {"embedding_mask": torch.linalg.norm(F.softmax(m1, dim=2).permute(0, 2, 1),
+                                                            dim=-1, ord=2),
+                        "point_cloud": pc}
+
+        rows = [torch.cat((t, _unit(q)), dim=-1).reshape(-1, 1, 7)
+                for q, t in ((q1, t1), (q2, t2), (q3, t3), (q4, t4))]
+        return torch.cat(rows, dim=1), log_dict

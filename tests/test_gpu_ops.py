@@ -1,0 +1,250 @@
+"""GPU parity tests of the HIP operator stack against the CPU oracle (run with ``-m gpu``).
+
+Every call goes through the C ABI of libpwclo_hip.so (``pointnet2_ops._ext`` is a thin ctypes
+front-end).  Bars: bit-exact for every index output (FPS, knn, ball_query, three_nn) and for
+the copy / interpolation outputs whose operation order is fixed; 1e-5 relative for the atomic
+scatter-add gradients (order-dependent fp32 sums; oracle accumulates in double).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+from pwclonet_pylidarslam_amd.pointnet2_ops import _ext as E
+from pwclonet_pylidarslam_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def g(t, dev):
+    return t.to(dev)
+
+
+def rand_cloud(seed, b, n, scale=20.0):
+    gen = torch.Generator().manual_seed(seed)
+    return (torch.rand(b, n, 3, generator=gen) * 2 - 1) * scale
+
+
+# ---------------------------------------------------------------- furthest point sampling
+FPS_SHAPES = [(2, 8192, 2048), (2, 2048, 1024), (3, 1024, 256), (3, 256, 64), (2, 1024, 2048),
+              (2, 100, 50), (2, 63, 20), (1, 5000, 300), (2, 16384, 128), (1, 20000, 64),
+              (1, 30000, 12), (2, 1, 3), (2, 129, 129), (2, 511, 40), (2, 4096, 512), (1, 4097, 300)]
+
+
+@pytest.mark.parametrize("b,n,m", FPS_SHAPES)
+def test_fps_random(cuda, b, n, m):
+    x = rand_cloud(100 + n + m, b, n)
+    ref = O.furthest_point_sampling(x, m)
+    out = E.furthest_point_sampling(g(x, cuda), m).cpu()
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("n,m", [(512, 300), (1000, 700), (8192, 512), (64, 64), (300, 200)])
+def test_fps_exact_ties_lattice(cuda, n, m):
+    """Integer lattice + duplicates: almost every arg-max is an exact tie, so the result is
+    decided by the reference's tie rule (bit-reversed k mod bs, then k div bs)."""
+    gen = torch.Generator().manual_seed(n * 7 + m)
+    x = torch.randint(-3, 4, (3, n, 3), generator=gen).float()
+    ref = O.furthest_point_sampling(x, m)
+    out = E.furthest_point_sampling(g(x, cuda), m).cpu()
+    assert torch.equal(out, ref)
+
+
+def test_fps_origin_points_and_exhaustion(cuda):
+    """Zero padding is never sampled (|p|^2 <= 1e-3), index 0 is always first even when it is
+    padding, and once the valid points run out the reference keeps returning duplicates."""
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(3, 700, 3, generator=gen) * 2 - 1) * 10
+    x[0, :350] = 0.0                      # first half padding, incl. index 0
+    x[1, 100:] = 0.01                     # |p|^2 = 3e-4 <= 1e-3: skipped
+    x[2] = 0.0                            # nothing valid at all -> all zeros
+    m = 400
+    ref = O.furthest_point_sampling(x, m)
+    out = E.furthest_point_sampling(g(x, cuda), m).cpu()
+    assert torch.equal(out, ref)
+    assert (out[2] == 0).all()
+    assert (out[0, 1:] >= 350).all()   # padding (indices < 350) is never sampled after index 0
+
+
+def test_fps_kitti_shaped_batch32(cuda):
+    """Full benchmark size (B=32, N=8192 -> 2048): oracle parity on 2 clouds, plus
+    size-independent properties on all 32: first index 0, no repeated index."""
+    pc1, _, _, _ = synthetic.kitti_like_pair(77, 8192, 4)
+    x = torch.from_numpy(np.tile(pc1[:, :, :3], (8, 1, 1))).contiguous()
+    x = x + torch.arange(32).reshape(32, 1, 1) * 1e-3  # make the 32 clouds distinct
+    out = E.furthest_point_sampling(g(x, cuda), 2048).cpu()
+    assert (out[:, 0] == 0).all()
+    for b in range(32):
+        assert len(torch.unique(out[b])) == 2048
+    ref = O.furthest_point_sampling(x[:2].contiguous(), 2048)
+    assert torch.equal(out[:2], ref)
+
+
+# ---------------------------------------------------------------- gather / group (+ grads)
+@pytest.mark.parametrize("b,c,n,m", [(2, 3, 8192, 2048), (3, 3, 256, 64), (2, 7, 100, 33), (1, 64, 1024, 1)])
+def test_gather_points(cuda, b, c, n, m):
+    gen = torch.Generator().manual_seed(b * c + n)
+    p = torch.randn(b, c, n, generator=gen)
+    idx = torch.randint(0, n, (b, m), generator=gen, dtype=torch.int32)
+    assert torch.equal(E.gather_points(g(p, cuda), g(idx, cuda)).cpu(), O.gather_points(p, idx))
+    go = torch.randn(b, c, m, generator=gen)
+    ref = O.gather_points_grad(go, idx, n)
+    out = E.gather_points_grad(g(go, cuda), g(idx, cuda), n).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+
+
+GROUP_SHAPES = [(2, 3, 8192, 2048, 32), (2, 16, 2048, 1024, 32), (2, 64, 256, 64, 16),
+                (2, 64, 1024, 2048, 8), (2, 3, 256, 256, 6), (1, 5, 77, 13, 3), (2, 64, 256, 256, 4),
+                (1, 129, 50, 7, 5)]
+
+
+@pytest.mark.parametrize("b,c,n,s,k", GROUP_SHAPES)
+def test_group_points(cuda, b, c, n, s, k):
+    gen = torch.Generator().manual_seed(c * n + s * k)
+    p = torch.randn(b, c, n, generator=gen)
+    idx = torch.randint(0, n, (b, s, k), generator=gen, dtype=torch.int32)
+    out = E.group_points(g(p, cuda), g(idx, cuda)).cpu()
+    assert torch.equal(out, O.group_points(p, idx))
+
+
+@pytest.mark.parametrize("b,c,n,s,k", [(2, 16, 2048, 1024, 32), (2, 64, 256, 64, 16), (1, 5, 77, 13, 3)])
+def test_group_points_grad(cuda, b, c, n, s, k):
+    gen = torch.Generator().manual_seed(c * n + s * k + 1)
+    go = torch.randn(b, c, s, k, generator=gen)
+    idx = torch.randint(0, n, (b, s, k), generator=gen, dtype=torch.int32)
+    out = E.group_points_grad(g(go, cuda), g(idx, cuda), n).cpu()
+    torch.testing.assert_close(out, O.group_points_grad(go, idx, n), rtol=1e-5, atol=1e-4)
+
+
+def test_group_points_linearity_full_size(cuda):
+    """B=32 at the largest call of the forward (C=64,N=1024,S=2048,K=8): group(a*x+y) ==
+    a*group(x)+group(y) exactly for power-of-two a, and every element equals its source."""
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(32, 64, 1024, generator=gen).to(cuda)
+    y = torch.randn(32, 64, 1024, generator=gen).to(cuda)
+    idx = torch.randint(0, 1024, (32, 2048, 8), generator=gen, dtype=torch.int32).to(cuda)
+    gx, gy = E.group_points(x, idx), E.group_points(y, idx)
+    assert torch.equal(E.group_points(2 * x + y, idx), 2 * gx + gy)
+    ref = torch.gather(x.unsqueeze(2).expand(-1, -1, 2048, -1), 3,
+                       idx.long().unsqueeze(1).expand(-1, 64, -1, -1))
+    assert torch.equal(gx, ref)
+
+
+# ---------------------------------------------------------------- ball query
+@pytest.mark.parametrize("b,m,n,k,r", [(2, 2048, 8192, 32, 0.5), (2, 1024, 2048, 32, 1.0),
+                                        (2, 256, 1024, 16, 2.0), (2, 64, 256, 16, 4.0),
+                                        (1, 33, 100, 5, 1e-6), (1, 33, 100, 7, 1e6)])
+def test_ball_query(cuda, b, m, n, k, r):
+    xyz = rand_cloud(3 * m + n, b, n, scale=8.0)
+    new_xyz = xyz[:, :m].contiguous() + 0.01
+    ref = O.ball_query(new_xyz, xyz, r, k)
+    out = E.ball_query(g(new_xyz, cuda), g(xyz, cuda), r, k).cpu()
+    assert torch.equal(out, ref)
+
+
+# ---------------------------------------------------------------- three_nn / three_interpolate
+@pytest.mark.parametrize("b,n,m", [(2, 256, 64), (2, 1024, 256), (2, 2048, 1024), (1, 10, 2), (1, 10, 1),
+                                   (1, 70, 3)])
+def test_three_nn(cuda, b, n, m):
+    unknown = rand_cloud(n + m, b, n)
+    known = rand_cloud(n * m + 1, b, m)
+    if m >= 4:
+        known[:, 1] = known[:, 0]  # exact duplicate: tie must go to the lower index
+    d_ref, i_ref = O.three_nn(unknown, known)
+    d, i = E.three_nn(g(unknown, cuda), g(known, cuda))
+    assert torch.equal(i.cpu(), i_ref)
+    assert torch.equal(d.cpu(), d_ref)
+
+
+@pytest.mark.parametrize("b,c,m,n", [(2, 64, 64, 256), (2, 64, 256, 1024), (1, 5, 9, 31)])
+def test_three_interpolate(cuda, b, c, m, n):
+    gen = torch.Generator().manual_seed(c + m + n)
+    p = torch.randn(b, c, m, generator=gen)
+    idx = torch.randint(0, m, (b, n, 3), generator=gen, dtype=torch.int32)
+    w = torch.rand(b, n, 3, generator=gen)
+    out = E.three_interpolate(g(p, cuda), g(idx, cuda), g(w, cuda)).cpu()
+    assert torch.equal(out, O.three_interpolate(p, idx, w))
+    go = torch.randn(b, c, n, generator=gen)
+    gout = E.three_interpolate_grad(g(go, cuda), g(idx, cuda), g(w, cuda), m).cpu()
+    torch.testing.assert_close(gout, O.three_interpolate_grad(go, idx, w, m), rtol=1e-5, atol=1e-4)
+
+
+# ---------------------------------------------------------------- knn
+KNN_SHAPES = [  # (K, N, S) of the 23 calls in one forward, B=2
+    (32, 8192, 2048), (32, 2048, 1024), (16, 1024, 256), (16, 256, 64), (32, 256, 256), (4, 256, 256),
+    (8, 64, 256), (6, 256, 256), (8, 256, 1024), (6, 1024, 1024), (4, 1024, 1024), (8, 1024, 2048),
+    (6, 2048, 2048), (4, 2048, 2048),
+    # edge shapes
+    (1, 97, 33), (5, 5, 7), (64, 64, 3), (64, 1000, 17), (3, 130, 1), (32, 33, 50)]
+
+
+@pytest.mark.parametrize("k,n,s", KNN_SHAPES)
+def test_knn_random(cuda, k, n, s):
+    xyz = rand_cloud(k * 1000 + n + s, 2, n)
+    new_xyz = rand_cloud(k * 1000 + n + s + 1, 2, s)
+    if s <= n:
+        new_xyz[0] = xyz[0, :s]  # self-queries in one cloud: first neighbour is the point itself
+    d_ref, i_ref = O.knn_point_with_dist(k, xyz, new_xyz)
+    d, i = E.knn_point(k, g(xyz, cuda), g(new_xyz, cuda), return_dist=True)
+    assert torch.equal(i.cpu(), i_ref)
+    assert torch.equal(d.cpu(), d_ref)   # also proves the device sqrtf is correctly rounded
+
+
+def test_knn_duplicates_and_lattice(cuda):
+    """Exact distance ties (duplicated points, integer lattice): lower index first."""
+    gen = torch.Generator().manual_seed(11)
+    xyz = torch.randint(-4, 5, (2, 2000, 3), generator=gen).float()
+    new_xyz = xyz[:, ::7].contiguous()
+    for k in (4, 16, 32):
+        d_ref, i_ref = O.knn_point_with_dist(k, xyz, new_xyz)
+        d, i = E.knn_point(k, g(xyz, cuda), g(new_xyz, cuda), return_dist=True)
+        assert torch.equal(i.cpu(), i_ref)
+        assert torch.equal(d.cpu(), d_ref)
+
+
+def test_knn_kitti_shaped_batch32_properties(cuda):
+    """B=32, N=8192, S=2048, K=32: distances ascending, self-match first, no repeated index;
+    oracle parity on one cloud."""
+    pc1, _, _, _ = synthetic.kitti_like_pair(78, 8192, 2)
+    x = torch.from_numpy(np.tile(pc1[:, :, :3], (16, 1, 1))).contiguous()
+    x = x * (1 + torch.arange(32).reshape(32, 1, 1) * 1e-3)
+    q = x[:, :2048].contiguous()
+    d, i = E.knn_point(32, g(x, cuda), g(q, cuda), return_dist=True)
+    d, i = d.cpu(), i.cpu()
+    assert (d[:, :, 1:] >= d[:, :, :-1]).all()
+    assert (i[:, :, 0] == torch.arange(2048).reshape(1, -1)).all()
+    assert (torch.sort(i, dim=2)[0].diff(dim=2) > 0).all()
+    d_ref, i_ref = O.knn_point_with_dist(32, x[31:32].contiguous(), q[31:32].contiguous())
+    assert torch.equal(i[31:32], i_ref) and torch.equal(d[31:32], d_ref)
+
+
+def test_knn_rejects_bad_arguments(cuda):
+    xyz = rand_cloud(1, 1, 10).to(cuda)
+    with pytest.raises(RuntimeError):
+        E.knn_point(11, xyz, xyz)          # nsample > n
+    with pytest.raises(RuntimeError):
+        E.knn_point(65, rand_cloud(1, 1, 100).to(cuda), xyz)  # nsample > 64
+    with pytest.raises(RuntimeError):
+        E.knn_point(4, xyz.double(), xyz)  # dtype check, like CHECK_IS_FLOAT
+    with pytest.raises(RuntimeError):
+        E.group_points(xyz.cpu().transpose(1, 2).contiguous(), torch.zeros(1, 2, 2, dtype=torch.int32))
+
+
+# ---------------------------------------------------------------- quaternion warp
+def test_quat_warp(cuda):
+    from oracle import model as M
+    gen = torch.Generator().manual_seed(3)
+    xyz = (torch.rand(4, 3, 2048, generator=gen) * 2 - 1) * 30
+    q = torch.randn(4, 4, 1, generator=gen)
+    q = q / q.norm(dim=1, keepdim=True)
+    q[3] *= 1.7  # not normalised: exercises the 1/(|q|^2+1e-10) factor
+    t = torch.randn(4, 3, 1, generator=gen)
+    ref = M.warp(xyz, q, t)
+    out = E.quat_warp(g(xyz, cuda), g(q, cuda), g(t, cuda)).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    # known answer: rotate (1,0,0) by 90 deg about z, then translate
+    one = torch.tensor([[[1.0], [0.0], [0.0]]])
+    qz = torch.tensor([[[np.cos(np.pi / 4)], [0.0], [0.0], [np.sin(np.pi / 4)]]], dtype=torch.float32)
+    tt = torch.tensor([[[1.0], [2.0], [3.0]]])
+    got = E.quat_warp(one.to(cuda), qz.to(cuda), tt.to(cuda)).cpu().flatten()
+    torch.testing.assert_close(got, torch.tensor([1.0, 3.0, 3.0]), rtol=0, atol=1e-6)
