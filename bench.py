@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--npoints", type=int, default=8192)
     ap.add_argument("--log-mode", default="host", choices=["host", "device", "none"],
                     help="host = the reference's in-forward D2H log_dict (default)")
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
+                    help="graph = replay one captured hipGraph per step (default); eager = Python launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4)
     args = ap.parse_args()
@@ -129,10 +131,17 @@ def main():
                         log_mode=args.log_mode)).to(dev).eval()
     x1, x2 = make_batch(args.batch, args.npoints, 1000 + rank, dev)
 
-    def step():
-        with torch.no_grad():
-            pose, _ = net(x1, None, x2, None)
-        return pose
+    if args.launch == "graph":
+        from pwclonet_pylidarslam_amd.graphed import GraphedForward
+        graphed = GraphedForward(net)
+
+        def step():
+            return graphed(x1, x2)
+    else:
+        def step():
+            with torch.no_grad():
+                pose, _ = net(x1, None, x2, None)
+            return pose
 
     for _ in range(args.warmup):
         step()
@@ -171,7 +180,8 @@ def main():
                                    % (args.npoints, args.batch),
                        "global_batch": world * args.batch, "npoints": args.npoints,
                        "parallelism": "replicas x%d (no forward collective)" % world,
-                       "log_dict": args.log_mode},
+                       "log_dict": args.log_mode if args.launch == "eager" else "device (graph replay)",
+                       "launch": args.launch},
             "roofline": {"kernel": "group_points_kernel", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "launches": launches,

@@ -40,8 +40,38 @@ static inline int ref_opt_n_threads(int work_size) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
-// Wave-wide reductions through DPP row operations + cross-row broadcasts (no LDS traffic).
-// After the call every lane holds the result.
+// ---- DPP helpers (gfx9 encodings: quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140).
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// Reduce over each row of 16 lanes (result in every lane of the row): xor-1, xor-2 inside quads,
+// then mirror within 8 and within 16.  4 VALU-rate steps, no LDS crossbar round trips.
+template <typename Op>
+__device__ __forceinline__ unsigned row16_allreduce_u32(unsigned v, Op op) {
+  v = op(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = op(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = op(v, dpp_u32<0x141>(v));  // row_half_mirror
+  v = op(v, dpp_u32<0x140>(v));  // row_mirror
+  return v;
+}
+
+// Full-wave reduction; the result is wave-uniform (lives in SGPRs after the readlanes).
+template <typename Op>
+__device__ __forceinline__ unsigned wave_reduce_u32(unsigned v, Op op) {
+  v = row16_allreduce_u32(v, op);
+  const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+  const unsigned r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32);
+  const unsigned r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return op(op(r0, r1), op(r2, r3));
+}
+
+struct OpMaxU32 { __device__ __forceinline__ unsigned operator()(unsigned a, unsigned b) const { return a > b ? a : b; } };
+struct OpMinU32 { __device__ __forceinline__ unsigned operator()(unsigned a, unsigned b) const { return a < b ? a : b; } };
+
+// Shuffle-based all-reduce (ds_bpermute); only for cold paths.
 template <typename Op>
 __device__ __forceinline__ float wave_allreduce_f32(float v, Op op) {
 #pragma unroll

@@ -16,40 +16,60 @@
 // maximises the distance and, among equal distances, minimises pri.  A thread whose points are
 // all skipped (|p|^2 <= 1e-3) or out of range contributes nothing; if no thread has a
 // candidate the result is index 0, as in the reference (best = -1, besti = 0 everywhere).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace pwclo {
 
 constexpr int PRI_SHIFT = 23;  // k div bs < 2^23
-constexpr int FPS_SLOT_BYTES = 256;  // 2 x 16 u64 wave slots in front of the LDS point table
+constexpr int FPS_SLOT_BYTES = 64;  // 3 rotating u64 arg-max slots in front of the LDS point table
 
 __device__ __forceinline__ unsigned fps_bitrev(unsigned v, int bits) {
   return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
 }
 
-// T threads, PPT points per thread (point k = tid + T*j).  T is a multiple of bs, so all points
-// of a thread share k mod bs and their priorities grow with j: a strict > in j order keeps the
-// thread's best-priority maximum, exactly like the reference thread does.
-template <int T, int PPT, bool LDS_TABLE>
+// T threads; a thread owns PPT = I << E points.  The reference partitions the cloud over
+// bs = opt_n_threads(n) threads by k mod bs.  Here
+//   * T >= bs (E = 0): thread tid owns residue tid mod bs, points k = tid + T*i, i < I;
+//   * T <  bs (E = log2(bs/T)): thread tid owns the 2^E residues tid + T*u.  Their bit-reversed
+//     ranks are bitrev(tid) + bitrev_E(u), so visiting u in bit-reversed order (u' = 0..2^E-1,
+//     u = bitrev_E(u')) visits residues by ascending rank; k = tid + T*u + bs*i.
+// Either way the thread's local order j = u'*I + i has strictly increasing priority
+// pri = (rank << 23) | (k div bs), so a strict > over j keeps exactly the candidate the
+// reference's per-thread scan + tie-keeping tree would keep.
+//
+// Distances are >= +0, so their IEEE bit patterns order like signed integers; the running
+// distance of a never-eligible point is -1.0f (a negative int).  min / compare / max therefore
+// run as 1-instruction integer ops with no NaN-canonicalisation, and the wave arg-max is two
+// DPP row reductions (value, then priority among the lanes holding it) finished by readlanes.
+// Cross-wave: lane 0 of each wave does ONE ds_max_u64 on a rotating LDS slot, one barrier, one
+// broadcast read.  Slot (it-1)%3 is cleared right after barrier `it` (every wave has read it
+// before arriving there, nobody adds to it before barrier it+1).
+template <int T, int E, int I, bool LDS_TABLE>
 __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int log2bs,
                                                     const float *__restrict__ dataset,
                                                     int *__restrict__ idxs) {
+  constexpr int PPT = I << E;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [2][16]
+  unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [3] rotating
   float4 *table = reinterpret_cast<float4 *>(smem + FPS_SLOT_BYTES);         // [n] when LDS_TABLE
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
   constexpr int NW = T / 64;
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   int *out = idxs + (size_t)blockIdx.x * m;
+  const int kstride = E == 0 ? T : bs;  // distance between consecutive points of one residue
 
-  float x[PPT], y[PPT], z[PPT], td[PPT];
+  float x[PPT], y[PPT], z[PPT];
+  int td[PPT];  // running min distance as IEEE bits; bits(-1.0f) < 0 marks "never a candidate"
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
-    const int k = tid + T * j;
-    float px = 0.f, py = 0.f, pz = 0.f, t0 = -1.0f;  // -1: never a candidate
+    const int up = j / I, i = j % I;
+    const int u = E == 0 ? 0 : (int)(__brev((unsigned)up) >> (32 - (E == 0 ? 1 : E)));
+    const int k = tid + T * u + kstride * i;
+    float px = 0.f, py = 0.f, pz = 0.f, t0 = -1.0f;
     if (k < n) {
       px = pts[k * 3 + 0];
       py = pts[k * 3 + 1];
@@ -58,12 +78,16 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
       if (!((double)mag <= 1e-3)) t0 = 1e10f;  // sampling.cpp:74-76 initial temp
       if (LDS_TABLE) table[k] = make_float4(px, py, pz, 0.f);
     }
-    x[j] = px; y[j] = py; z[j] = pz; td[j] = t0;
+    x[j] = px; y[j] = py; z[j] = pz; td[j] = __float_as_int(t0);
   }
-  const int tpb = T / bs;  // priority step between consecutive points of one thread
+  // priority of local point j: pri_base + (u' << 23) + qstep * i
   const unsigned pri_base = (fps_bitrev((unsigned)(tid & (bs - 1)), log2bs) << PRI_SHIFT) |
-                            (unsigned)(tid / bs);
-  if (tid == 0) out[0] = 0;
+                            (E == 0 ? (unsigned)(tid / bs) : 0u);
+  const unsigned qstep = E == 0 ? (unsigned)(T / bs) : 1u;
+  if (tid == 0) {
+    out[0] = 0;
+    slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull;
+  }
   __syncthreads();
 
   int old = 0;
@@ -75,36 +99,32 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
     } else {
       x1 = pts[old * 3 + 0]; y1 = pts[old * 3 + 1]; z1 = pts[old * 3 + 2];
     }
-    float best = -1.0f;
+    int best = __float_as_int(-1.0f);
     int bestj = 0;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const float dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1;
       const float d = dx * dx + dy * dy + dz * dz;  // -ffp-contract=off: (a+b)+c, no FMA
-      const float d2 = fminf(d, td[j]);
+      const int d2 = min(__float_as_int(d), td[j]); // == fminf for d >= +0, td >= +0 or td == -1.0f
       td[j] = d2;
       const bool better = d2 > best;
       bestj = better ? j : bestj;
       best = better ? d2 : best;
     }
-    // wave arg-max: max distance, then min priority among the lanes holding that distance
-    const float wmax = wave_allreduce_f32(best, [](float a, float b) { return fmaxf(a, b); });
-    unsigned pri = (best == wmax && best >= 0.0f) ? pri_base + (unsigned)(bestj * tpb) : 0xFFFFFFFFu;
-    pri = wave_allreduce_u32(pri, [](unsigned a, unsigned b) { return a < b ? a : b; });
-    unsigned long long key = 0ull;  // 0 = "no candidate in this wave"
-    if (wmax >= 0.0f)
-      key = ((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned long long)(0xFFFFFFFFu - pri);
+    // 0 = no candidate; otherwise bits+1 so that a legitimate distance of +0.0 stays distinct
+    const unsigned mine = best < 0 ? 0u : (unsigned)best + 1u;
+    const unsigned wmax = wave_reduce_u32(mine, OpMaxU32());
+    const unsigned mypri = pri_base + ((unsigned)(bestj / I) << PRI_SHIFT) + qstep * (unsigned)(bestj % I);
+    const unsigned cand = (mine == wmax && mine != 0u) ? mypri : 0xFFFFFFFFu;
+    const unsigned wpri = wave_reduce_u32(cand, OpMinU32());
+    unsigned long long key =
+        wmax == 0u ? 0ull : (((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wpri));
     if (NW > 1) {
-      unsigned long long *slot = slots + (it & 1) * 16;
-      if (lane == 0) slot[wave] = key;
+      unsigned long long *slot = slots + (it % 3);
+      if (lane == 0) atomicMax(slot, key);
       __syncthreads();
-      unsigned long long kmax = slot[0];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) {
-        const unsigned long long o = slot[w];
-        kmax = o > kmax ? o : kmax;
-      }
-      key = kmax;
+      key = *slot;
+      if (tid == 0) slots[(it + 2) % 3] = 0ull;
     }
     if (key == 0ull) {
       old = 0;
@@ -173,12 +193,12 @@ __global__ __launch_bounds__(T) void fps_stream_kernel(int n, int m, int bs, int
   }
 }
 
-template <int T, int PPT>
+template <int T, int E, int I>
 static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float *dataset, int *idxs) {
   const size_t table_bytes = FPS_SLOT_BYTES + (size_t)n * sizeof(float4);
   hipStream_t st = current_stream();
   if (table_bytes <= 160 * 1024) {
-    auto kern = fps_reg_kernel<T, PPT, true>;
+    auto kern = fps_reg_kernel<T, E, I, true>;
     static bool big_lds_enabled = false;  // per instantiation; raises the 64 KiB dynamic-LDS default
     if (table_bytes > 64 * 1024 && !big_lds_enabled) {
       (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -187,9 +207,27 @@ static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float 
     }
     hipLaunchKernelGGL(kern, dim3(b), dim3(T), table_bytes, st, n, m, bs, log2bs, dataset, idxs);
   } else {
-    hipLaunchKernelGGL((fps_reg_kernel<T, PPT, false>), dim3(b), dim3(T), FPS_SLOT_BYTES, st, n, m,
+    hipLaunchKernelGGL((fps_reg_kernel<T, E, I, false>), dim3(b), dim3(T), FPS_SLOT_BYTES, st, n, m,
                        bs, log2bs, dataset, idxs);
   }
+}
+
+// Threads per cloud as a function of n (measured on MI355X, tools/microbench.py).
+// PWCLO_FPS_THREADS=<64|128|256|512|1024> overrides it for experiments.
+static int fps_pick_threads(int n, int bs) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char *e = getenv("PWCLO_FPS_THREADS");
+    forced = e ? atoi(e) : 0;
+  }
+  int T;
+  if (forced == 64 || forced == 128 || forced == 256 || forced == 512 || forced == 1024) T = forced;
+  else if (n <= 256) T = 64;     // single wave: no LDS exchange, no barrier (342 ns/iter at n=256)
+  else if (n <= 4096) T = 256;   // 505 ns/iter at n=2048 (512 threads: 573, 128: 671)
+  else T = 512;                  // 916 ns/iter at n=8192 (1024 threads: 988, 256: 1010)
+  if (T > 512 && n <= 512) T = 512;
+  (void)bs;
+  return T;
 }
 
 // out[b,c,j] = points[b,c,idx[b,j]]; grid (ceil(m/256), c, b) so that small m still fills CUs.
@@ -227,25 +265,37 @@ extern "C" void furthest_point_sampling_kernel_wrapper(int b, int n, int m, cons
   const int bs = ref_opt_n_threads(n);
   int log2bs = 0;
   while ((1 << log2bs) < bs) ++log2bs;
-  // Thread count: a multiple of bs (see kernel comment); 1024 threads once a cloud has more than
-  // 4096 points so that at most 16 points sit in one thread's registers up to n = 16384.
-  int T = bs < 64 ? 64 : bs;
-  if (n > 4096) T = 1024;
-  int ppt = ceil_div(n, T);
-  if (n > 16384 && n <= 24576) { T = 512; ppt = ceil_div(n, T); }
-#define FPS_CASE(TT, PP)                                                   \
-  if (T == TT && ppt <= PP) {                                              \
-    launch_fps_reg<TT, PP>(b, n, m, bs, log2bs, dataset, idxs);           \
+  int T = fps_pick_threads(n, bs);
+  int E = 0;
+  while ((T << E) < bs) ++E;                  // T < bs: a thread owns 2^E residues
+  int I = ceil_div(n, E == 0 ? T : bs);       // points per residue per thread
+  if (T == 1024 && I > 16) { T = 512; E = 0; I = ceil_div(n, 512); }   // VGPR budget at 16 waves
+#define FPS_CASE(TT, EE, II)                                               \
+  if (T == TT && E == EE && I <= II) {                                     \
+    launch_fps_reg<TT, EE, II>(b, n, m, bs, log2bs, dataset, idxs);       \
     check_launch("furthest_point_sampling");                              \
     return;                                                                \
   }
-  FPS_CASE(64, 1) FPS_CASE(64, 2)
-  FPS_CASE(128, 1) FPS_CASE(128, 2)
-  FPS_CASE(256, 1) FPS_CASE(256, 2)
-  FPS_CASE(512, 1) FPS_CASE(512, 2) FPS_CASE(512, 4) FPS_CASE(512, 8)
-  FPS_CASE(1024, 8) FPS_CASE(1024, 16)
-  FPS_CASE(512, 48)
+  if (T == 1024) { FPS_CASE(1024, 0, 8) FPS_CASE(1024, 0, 16) }
+  if (T == 512) { FPS_CASE(512, 0, 1) FPS_CASE(512, 0, 2) FPS_CASE(512, 0, 4) FPS_CASE(512, 0, 8)
+                  FPS_CASE(512, 0, 16) FPS_CASE(512, 0, 48) }
+  if (T == 256) { FPS_CASE(256, 0, 1) FPS_CASE(256, 0, 2)
+                  FPS_CASE(256, 1, 1) FPS_CASE(256, 1, 2) FPS_CASE(256, 1, 4) FPS_CASE(256, 1, 8)
+                  FPS_CASE(256, 1, 16) FPS_CASE(256, 1, 32) }
+  if (T == 128) { FPS_CASE(128, 0, 1) FPS_CASE(128, 0, 2)
+                  FPS_CASE(128, 1, 1) FPS_CASE(128, 1, 2)
+                  FPS_CASE(128, 2, 1) FPS_CASE(128, 2, 2) FPS_CASE(128, 2, 4) FPS_CASE(128, 2, 8)
+                  FPS_CASE(128, 2, 16) }
+  if (T == 64) { FPS_CASE(64, 0, 1) FPS_CASE(64, 0, 2)
+                 FPS_CASE(64, 1, 1) FPS_CASE(64, 1, 2)
+                 FPS_CASE(64, 2, 1) FPS_CASE(64, 2, 2)
+                 FPS_CASE(64, 3, 1) FPS_CASE(64, 3, 2) FPS_CASE(64, 3, 4) FPS_CASE(64, 3, 8) }
 #undef FPS_CASE
+  if (n <= 24576) {  // register-resident fallback (large clouds, or a forced T without a case)
+    launch_fps_reg<512, 0, 48>(b, n, m, bs, log2bs, dataset, idxs);
+    check_launch("furthest_point_sampling");
+    return;
+  }
   PWCLO_REQUIRE(temp != nullptr,
                 "furthest_point_sampling: n=%d needs the (b,n) temp buffer pre-filled with 1e10", n);
   hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, current_stream(), n, m, bs,
