@@ -110,6 +110,8 @@ def main():
                     help="host = the reference's in-forward D2H log_dict (default)")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph = replay one captured hipGraph per step (default); eager = Python launches")
+    ap.add_argument("--unfused", action="store_true",
+                    help="reference-shaped module graph on the HIP ops (torch conv/BN) instead of the fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4)
     args = ap.parse_args()
@@ -129,6 +131,8 @@ def main():
     torch.manual_seed(1234)
     net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(dev), scalar_last=False,
                         log_mode=args.log_mode)).to(dev).eval()
+    if not args.unfused:
+        net.prepare_fused()
     x1, x2 = make_batch(args.batch, args.npoints, 1000 + rank, dev)
 
     if args.launch == "graph":
@@ -181,7 +185,8 @@ def main():
                        "global_batch": world * args.batch, "npoints": args.npoints,
                        "parallelism": "replicas x%d (no forward collective)" % world,
                        "log_dict": args.log_mode if args.launch == "eager" else "device (graph replay)",
-                       "launch": args.launch},
+                       "launch": args.launch, "kernels": "module graph + torch conv/BN" if args.unfused
+                       else "fused gather+MFMA-MLP kernels (BN folded)"},
             "roofline": {"kernel": "group_points_kernel", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "launches": launches,

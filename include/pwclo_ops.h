@@ -120,6 +120,65 @@ void knn_point_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz
 void quat_warp_kernel_wrapper(int b, int n, const float *xyz, const float *q, const float *t,
                               float *out);
 
+/* ---- 3. fused eval-mode layers ------------------------------------------------------------- */
+/* One launch per reference module forward (eval mode: BatchNorm running statistics folded into
+ * the packed weights, no dropout).  Feature tensors are POINT-MAJOR (b, n, c) fp32 with c a
+ * multiple of 16; `packed_w` is produced by pwclonet_pylidarslam_amd/fused.py (layout in
+ * csrc/mlp_core.hpp).  Unsupported channel configurations record PWCLO_EINVAL. */
+
+/* PointnetSAModulePWCLONet.forward after FPS/knn (pointnet2_modules.py:205-243): gather the k
+ * neighbours idx[b,s,:] of every query, subtract the query centre, run the 3-layer shared MLP
+ * (padded widths c1,c2,c3) and max over the neighbours.  xyz (b,n,3), new_xyz (b,s,3), feat
+ * (b,n,c_feat) or NULL when c_feat == 0 (level-0 input [xyz_diff, grouped_xyz]), idx (b,s,k)
+ * i32, out (b,s,c3). */
+void sa_fused_kernel_wrapper(int b, int n, int s, int k, int c_feat, int c1, int c2, int c3,
+                             const float *xyz, const float *new_xyz, const float *feat,
+                             const int *idx, const float *packed_w, float *out);
+
+/* furthest_point_sampling_kernel_wrapper that also writes the sampled coordinates new_xyz (b,m,3)
+ * = dataset[b, idxs[b,j], :] (the gather_operation that always follows FPS in the set-abstraction
+ * layer, pointnet2_modules.py:196-203); new_xyz may be NULL. */
+void furthest_point_sampling_xyz_kernel_wrapper(int b, int n, int m, const float *dataset,
+                                                float *temp, int *idxs, float *new_xyz);
+
+/* quat_warp_kernel_wrapper on point-major clouds: xyz, out (b,n,3). */
+void quat_warp_pm_kernel_wrapper(int b, int n, const float *xyz, const float *q, const float *t,
+                                 float *out);
+
+/* PointnetFPModulePWCLONet.forward, knn branch up to the max over neighbours
+ * (pointnet2_modules.py:479-506): gather feat1 (b,n,64) and xyz1 (b,n,3) at idx (b,s,k<=8), append
+ * xyz1[nbr]-xyz2[s], shared MLP 67->128->64, max over k.  out (b,s,64). */
+void upconv_fused_kernel_wrapper(int b, int n, int s, int k, const float *xyz2, const float *xyz1,
+                                 const float *feat1, const int *idx, const float *packed_w,
+                                 float *out);
+
+/* Shared MLP (1 or 2 layers, padded widths w1,w2; w2 = 0 for one layer) over the channel
+ * concatenation of up to three per-point tensors src_i (b,s,c_i): the set-upconv post_mlp
+ * (pointnet2_modules.py:508-515) and FlowPredictor.forward (PW/flowpredictor.py:53-83). */
+void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int c2, int w1, int w2,
+                                    const float *src0, const float *src1, const float *src2,
+                                    const float *packed_w, float *out);
+
+/* CostVolume.forward (PW/costvolume.py:63-190) in three launches.
+ * a1: per (query s, neighbour k) pixel: mlp_convs([geometry10 | feat1[s] | feat2[idx]]) -> pix
+ *     (b, s*kp, 64), kp = k rounded up to 8/16/32.  xyz1 (b,s,3), feat1 (b,s,c), xyz2 (b,n,3),
+ *     feat2 (b,n,c), idx (b,s,k).
+ * a2: mlp_conv_xyz_1(geometry10), mlp2_convs, softmax over k, sum_k w*pix -> out (b,s,64).
+ * b : second aggregate over the k<=4 frame-1 neighbours idx (b,s,k) of each frame-1 point:
+ *     mlp_conv_xyz_2, mlp3_convs([enc | feat1[s] | first[idx]]), softmax, sum_k w*first[idx]. */
+void cv_fused_a1_kernel_wrapper(int b, int n, int s, int k, int c, const float *xyz1,
+                                const float *feat1, const float *xyz2, const float *feat2,
+                                const int *idx, const float *packed_w, float *pix);
+void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const float *xyz1, const float *xyz2,
+                                const int *idx, const float *packed_w, const float *pix, float *out);
+void cv_fused_b_kernel_wrapper(int b, int s, int k, int c, const float *xyz1, const float *feat1,
+                               const float *first, const int *idx, const float *packed_w, float *out);
+
+/* out[b,c] = sum_n emb[b,n,c] * softmax_n(mask[b,n,c]) for 64-channel point-major emb/mask
+ * (b,n,64): F.softmax(mask, dim=2) + the masked sum of PoseCalculator.forward
+ * (PW/pose_calculator.py:58). */
+void masked_pool_kernel_wrapper(int b, int n, const float *emb, const float *mask, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,514 @@
+// Fused eval-mode layers of the pose warp-refinement path (gfx950): set-upconv, point-wise MLPs
+// (post-MLP, flow / mask predictors), the attentive cost volume and the mask-softmax pooling of
+// the pose head.  All built on mlp_core.hpp: activations stay in registers across a stack's
+// layers, packed weights stay resident in LDS, persistent workgroups stream 16-pixel blocks.
+//
+// The cost volume (PW/costvolume.py:63-190) is cut where an activation has to outlive a weight
+// set that no longer fits in the 160 KiB LDS next to the following one:
+//   cv_a1: [geometry10 | centre feat | gathered feat] -> mlp_convs (128,64,64) -> feat (per pixel)
+//   cv_a2: geometry10 -> mlp_conv_xyz_1 ; [enc | feat] -> mlp2_convs (128,64) -> softmax over the
+//          neighbours -> sum_k w * feat                                   ("first aggregate", :86-144)
+//   cv_b : geometry10' -> mlp_conv_xyz_2 ; [enc2 | centre feat | gathered first] -> mlp3_convs
+//          -> softmax over the neighbours -> sum_k w * gathered first     ("second aggregate", :146-188)
+// The only materialised intermediate is cv_a1's 64-channel per-pixel feature (written once, read
+// once); the reference materialises > 10 (B,C,S,K) tensors for the same result.
+#include <math.h>
+
+#include "mlp_core.hpp"
+
+namespace pwclo {
+
+constexpr int FL_WAVES = 8;
+
+// ---- shared prologue pieces ----------------------------------------------------------------------
+
+// 16-channel geometry block [p(3), q(3), q-p(3), |q-p|, 0 x 6] (costvolume.py:92-105) for lane
+// group g: g0 = (px,py,pz,qx), g1 = (qy,qz,dx,dy), g2 = (dz,euc,0,0), g3 = 0.
+__device__ __forceinline__ f32x4 geometry_block(const float *p, const float *q, int g) {
+  const float px = p[0], py = p[1], pz = p[2], qx = q[0], qy = q[1], qz = q[2];
+  const float dx = qx - px, dy = qy - py, dz = qz - pz;
+  const float euc = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-20f);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (g == 0) v = f32x4{px, py, pz, qx};
+  if (g == 1) v = f32x4{qy, qz, dx, dy};
+  if (g == 2) v = f32x4{dz, euc, 0.f, 0.f};
+  return v;
+}
+
+template <int NB>
+__device__ __forceinline__ void load_row_blocks(f32x4 *dst, int stride_p, const float *row, int g) {
+#pragma unroll
+  for (int m = 0; m < NB; ++m) dst[m * stride_p] = *reinterpret_cast<const f32x4 *>(row + 16 * m + 4 * g);
+}
+
+// Softmax over the K neighbours of each query (dim=3 of the reference's (B,C,S,K) tensor) and
+// weighted sum of `val`; logits are post-ReLU (>= 0), padded neighbour slots carry weight 0.
+// Returns, in every lane of a neighbour group, sum_k softmax(x)_k * val_k per component.
+template <int KP, int P>
+__device__ __forceinline__ void softmax_weighted_sum(f32x4 (&res)[P], const f32x4 (&x)[P],
+                                                     const f32x4 (&val)[P], const bool (&padded)[P]) {
+  constexpr int GROUP = KP < 16 ? KP : 16;
+  constexpr int BPQ = KP > 16 ? KP / 16 : 1;
+  const float NEG_INF = __int_as_float(0xff800000);
+#pragma unroll
+  for (int p = 0; p < P; p += BPQ) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float xv[BPQ];
+      float mx = NEG_INF;
+#pragma unroll
+      for (int e = 0; e < BPQ; ++e) {
+        xv[e] = padded[p + e] ? NEG_INF : x[p + e][c];
+        mx = (__float_as_int(xv[e]) > __float_as_int(mx)) ? xv[e] : mx;  // values >= 0 or -inf
+      }
+      mx = group_max_nonneg<GROUP>(mx);
+      float den = 0.f, num = 0.f;
+#pragma unroll
+      for (int e = 0; e < BPQ; ++e) {
+        const float ex = padded[p + e] ? 0.f : expf(xv[e] - mx);
+        den += ex;
+        num += ex * val[p + e][c];
+      }
+      den = group_sum<GROUP>(den);
+      num = group_sum<GROUP>(num);
+      const float r = num / den;
+#pragma unroll
+      for (int e = 0; e < BPQ; ++e) res[p + e][c] = r;
+    }
+  }
+}
+
+#define PWCLO_TILE_LOOP(KP_, P_, S_, B_)                                                           \
+  constexpr int TILE = 16 * (P_);                                                                   \
+  const int pix_per_cloud = (S_) * (KP_);                                                           \
+  const int tiles_per_cloud = (pix_per_cloud + TILE - 1) / TILE;                                    \
+  const int ntiles = (B_) * tiles_per_cloud;                                                        \
+  for (int t = blockIdx.x * FL_WAVES + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * FL_WAVES)
+
+// ---- set-upconv: PointnetFPModulePWCLONet, knn branch up to the max (pointnet2_modules.py:479-506) --
+struct UpconvArgs {
+  const float *xyz2;    // (B,S,3) fine points (queries)
+  const float *xyz1;    // (B,N,3) coarse points
+  const float *feat1;   // (B,N,64) coarse features, point-major
+  const int *idx;       // (B,S,K)
+  const float *w;       // packed [64 feat | diff block] -> 128 -> 64
+  float *out;           // (B,S,64)
+  int B, N, S, K;
+};
+
+template <int KP, int P>
+__global__ __launch_bounds__(FL_WAVES * 64) void upconv_kernel(UpconvArgs a) {
+  constexpr int NBI = 5, B1 = 8, B2 = 4;
+  constexpr int W1 = layer_floats(NBI, B1), W2 = layer_floats(B1, B2);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, W1 + W2);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  PWCLO_TILE_LOOP(KP, P, a.S, a.B) {
+    const int b = t / tiles_per_cloud;
+    const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    f32x4 in[NBI][P];
+    int sq[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const PixelMap<KP> pm(pix0 + 16 * p + j);
+      const bool valid = pm.s < a.S;
+      const int s = valid ? pm.s : a.S - 1;
+      const int k = pm.k < a.K ? pm.k : 0;
+      sq[p] = valid ? s : -1;
+      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
+      load_row_blocks<4>(&in[0][p], P, a.feat1 + ((size_t)b * a.N + nbr) * 64, g);
+      const float *c = a.xyz2 + ((size_t)b * a.S + s) * 3;
+      const float *q = a.xyz1 + ((size_t)b * a.N + nbr) * 3;
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+      if (g == 0) d = f32x4{q[0] - c[0], q[1] - c[1], q[2] - c[2], 0.f};
+      in[4][p] = d;
+    }
+    f32x4 h1[B1][P], h2[B2][P];
+    mlp_layer<NBI, B1, P, true>(h1, in, lds_w, lane);
+    mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    constexpr int GROUP = KP < 16 ? KP : 16;
+#pragma unroll
+    for (int o = 0; o < B2; ++o) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        f32x4 v = h2[o][p];
+        v.x = group_max_nonneg<GROUP>(v.x);
+        v.y = group_max_nonneg<GROUP>(v.y);
+        v.z = group_max_nonneg<GROUP>(v.z);
+        v.w = group_max_nonneg<GROUP>(v.w);
+        if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
+          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = v;
+      }
+    }
+  }
+}
+
+// ---- point-wise MLP over concatenated per-point sources (K = 1) ------------------------------------
+// post_mlp (pointnet2_modules.py:508-515), FlowPredictor (PW/flowpredictor.py:53-83).
+struct PointwiseArgs {
+  const float *src[3];  // (B,S,16*NB*) point-major, concatenated in this order
+  const float *w;       // packed layers
+  float *out;           // (B,S,16*BOUT)
+  int B, S;
+};
+
+template <int NB0, int NB1, int NB2, int B1, int B2 /*0 = single layer*/, int P>
+__global__ __launch_bounds__(FL_WAVES * 64) void pointwise_kernel(PointwiseArgs a) {
+  constexpr int NBI = NB0 + NB1 + NB2;
+  constexpr int W1 = layer_floats(NBI, B1);
+  constexpr int W2 = B2 > 0 ? layer_floats(B1, B2) : 0;
+  constexpr int BOUT = B2 > 0 ? B2 : B1;
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, W1 + W2);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  PWCLO_TILE_LOOP(1, P, a.S, a.B) {
+    const int b = t / tiles_per_cloud;
+    const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    f32x4 in[NBI][P];
+    int sq[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int s0 = pix0 + 16 * p + j;
+      const bool valid = s0 < a.S;
+      const int s = valid ? s0 : a.S - 1;
+      sq[p] = valid ? s : -1;
+      const size_t row = (size_t)b * a.S + s;
+      load_row_blocks<NB0>(&in[0][p], P, a.src[0] + row * (16 * NB0), g);
+      if (NB1 > 0) load_row_blocks<NB1>(&in[NB0][p], P, a.src[1] + row * (16 * NB1), g);
+      if (NB2 > 0) load_row_blocks<NB2>(&in[NB0 + NB1][p], P, a.src[2] + row * (16 * NB2), g);
+    }
+    f32x4 h1[B1][P];
+    mlp_layer<NBI, B1, P, true>(h1, in, lds_w, lane);
+    if constexpr (B2 > 0) {
+      f32x4 h2[B2][P];
+      mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+#pragma unroll
+      for (int o = 0; o < B2; ++o)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          if (sq[p] >= 0)
+            *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * (16 * BOUT) + 16 * o + 4 * g) = h2[o][p];
+    } else {
+#pragma unroll
+      for (int o = 0; o < B1; ++o)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          if (sq[p] >= 0)
+            *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * (16 * BOUT) + 16 * o + 4 * g) = h1[o][p];
+    }
+  }
+}
+
+// ---- cost volume ------------------------------------------------------------------------------------
+struct CVArgs {
+  const float *xyz1;    // (B,S,3) (warped) frame-1 points = queries
+  const float *feat1;   // (B,S,C) frame-1 features, point-major
+  const float *xyz2;    // (B,N,3) candidate points (frame 2 for a1/a2, frame 1 for b)
+  const float *feat2;   // a1: (B,N,C) frame-2 features; b: (B,S,64) first-aggregate result
+  const int *idx;       // (B,S,K)
+  const float *w;       // packed weights of this stage
+  float *pix;           // a1: out (B,S*KP,64); a2: in (same)
+  float *out;           // a2 / b: (B,S,64)
+  int B, N, S, K;
+};
+
+// a1: [geo | centre feat (CB blocks) | gathered feat (CB blocks)] -> 128 -> 64 -> 64, stored per pixel.
+template <int CB, int KP, int P>
+__global__ __launch_bounds__(FL_WAVES * 64) void cv_a1_kernel(CVArgs a) {
+  constexpr int NBI = 1 + 2 * CB, B1 = 8, B2 = 4, B3 = 4, C = 16 * CB;
+  constexpr int W1 = layer_floats(NBI, B1), W2 = layer_floats(B1, B2), W3 = layer_floats(B2, B3);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, W1 + W2 + W3);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  PWCLO_TILE_LOOP(KP, P, a.S, a.B) {
+    const int b = t / tiles_per_cloud;
+    const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    f32x4 in[NBI][P];
+    int pixv[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int pix = pix0 + 16 * p + j;
+      const PixelMap<KP> pm(pix);
+      const bool valid = pm.s < a.S;
+      const int s = valid ? pm.s : a.S - 1;
+      const int k = pm.k < a.K ? pm.k : 0;
+      pixv[p] = valid ? pix : -1;
+      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
+      in[0][p] = geometry_block(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
+      load_row_blocks<CB>(&in[1][p], P, a.feat1 + ((size_t)b * a.S + s) * C, g);
+      load_row_blocks<CB>(&in[1 + CB][p], P, a.feat2 + ((size_t)b * a.N + nbr) * C, g);
+    }
+    f32x4 h1[B1][P], h2[B2][P], h3[B3][P];
+    mlp_layer<NBI, B1, P, true>(h1, in, lds_w, lane);
+    mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    mlp_layer<B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
+#pragma unroll
+    for (int o = 0; o < B3; ++o)
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (pixv[p] >= 0)
+          *reinterpret_cast<f32x4 *>(a.pix + ((size_t)b * pix_per_cloud + pixv[p]) * 64 + 16 * o + 4 * g) = h3[o][p];
+  }
+}
+
+// a2: enc = mlp_conv_xyz_1(geo); w = softmax_k(mlp2_convs([enc | feat])); out = sum_k w * feat.
+template <int KP, int P>
+__global__ __launch_bounds__(FL_WAVES * 64) void cv_a2_kernel(CVArgs a) {
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats(8, 8), W2 = layer_floats(8, 4);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, WX + W1 + W2);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  PWCLO_TILE_LOOP(KP, P, a.S, a.B) {
+    const int b = t / tiles_per_cloud;
+    const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    f32x4 geo[1][P], cat[8][P];
+    int sq[P];
+    bool padded[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int pix = pix0 + 16 * p + j;
+      const PixelMap<KP> pm(pix);
+      const bool valid = pm.s < a.S;
+      const int s = valid ? pm.s : a.S - 1;
+      padded[p] = pm.k >= a.K;
+      const int k = padded[p] ? 0 : pm.k;
+      sq[p] = valid ? s : -1;
+      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
+      geo[0][p] = geometry_block(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
+      const int pixc = valid ? pix : pix_per_cloud - 1;
+      load_row_blocks<4>(&cat[4][p], P, a.pix + ((size_t)b * pix_per_cloud + pixc) * 64, g);
+    }
+    f32x4 enc[4][P];
+    mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int p = 0; p < P; ++p) cat[m][p] = enc[m][p];
+    f32x4 h1[8][P], h2[4][P];
+    mlp_layer<8, 8, P, true>(h1, cat, lds_w + WX, lane);
+    mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+    constexpr int GROUP = KP < 16 ? KP : 16;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      f32x4 res[P];
+      softmax_weighted_sum<KP, P>(res, h2[o], cat[4 + o], padded);
+      constexpr int BPQ = KP > 16 ? KP / 16 : 1;
+#pragma unroll
+      for (int p = 0; p < P; p += BPQ)
+        if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
+          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = res[p];
+    }
+  }
+}
+
+// b: enc2 = mlp_conv_xyz_2(geo'); w = softmax_k(mlp3_convs([enc2 | centre feat | gathered first]));
+//    out = sum_k w * gathered first.  Candidates = the frame-1 points themselves (N == S).
+template <int CB, int KP, int P>
+__global__ __launch_bounds__(FL_WAVES * 64) void cv_b_kernel(CVArgs a) {
+  constexpr int NBI = 4 + CB + 4, C = 16 * CB;
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats(NBI, 8), W2 = layer_floats(8, 4);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, WX + W1 + W2);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  PWCLO_TILE_LOOP(KP, P, a.S, a.B) {
+    const int b = t / tiles_per_cloud;
+    const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    f32x4 geo[1][P], cat[NBI][P];
+    int sq[P];
+    bool padded[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const PixelMap<KP> pm(pix0 + 16 * p + j);
+      const bool valid = pm.s < a.S;
+      const int s = valid ? pm.s : a.S - 1;
+      padded[p] = pm.k >= a.K;
+      const int k = padded[p] ? 0 : pm.k;
+      sq[p] = valid ? s : -1;
+      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
+      geo[0][p] = geometry_block(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
+      load_row_blocks<CB>(&cat[4][p], P, a.feat1 + ((size_t)b * a.S + s) * C, g);
+      load_row_blocks<4>(&cat[4 + CB][p], P, a.feat2 + ((size_t)b * a.N + nbr) * 64, g);
+    }
+    f32x4 enc[4][P];
+    mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int p = 0; p < P; ++p) cat[m][p] = enc[m][p];
+    f32x4 h1[8][P], h2[4][P];
+    mlp_layer<NBI, 8, P, true>(h1, cat, lds_w + WX, lane);
+    mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+    constexpr int GROUP = KP < 16 ? KP : 16;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      f32x4 res[P];
+      softmax_weighted_sum<KP, P>(res, h2[o], cat[4 + CB + o], padded);
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
+          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = res[p];
+    }
+  }
+}
+
+// ---- pose head pooling: out[b,c] = sum_n emb[b,n,c] * softmax_n(mask[b,n,c]) ----------------------
+// (F.softmax(mask, dim=2) + PoseCalculator's masked sum, PW/pose_calculator.py:58; pwclo_net.py:172)
+constexpr int MP_PARTS = 16;  // 1024 threads: 64 channels x 16 point slices
+__global__ __launch_bounds__(64 * MP_PARTS) void masked_pool_kernel(int n, const float *__restrict__ emb,
+                                                                    const float *__restrict__ mask,
+                                                                    float *__restrict__ out) {
+  __shared__ float red[MP_PARTS][64];
+  __shared__ float red2[MP_PARTS][64];
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6, b = blockIdx.x;
+  const float *e = emb + (size_t)b * n * 64, *m = mask + (size_t)b * n * 64;
+  float mx = -INFINITY;
+  for (int i = part; i < n; i += MP_PARTS) mx = fmaxf(mx, m[(size_t)i * 64 + c]);
+  red[part][c] = mx;
+  __syncthreads();
+  mx = red[0][c];
+#pragma unroll
+  for (int q = 1; q < MP_PARTS; ++q) mx = fmaxf(mx, red[q][c]);
+  __syncthreads();
+  float den = 0.f, num = 0.f;
+  for (int i = part; i < n; i += MP_PARTS) {
+    const float ex = expf(m[(size_t)i * 64 + c] - mx);
+    den += ex;
+    num += ex * e[(size_t)i * 64 + c];
+  }
+  red[part][c] = den;
+  red2[part][c] = num;
+  __syncthreads();
+  if (part == 0) {
+    float d = 0.f, s = 0.f;
+#pragma unroll
+    for (int q = 0; q < MP_PARTS; ++q) { d += red[q][c]; s += red2[q][c]; }
+    out[b * 64 + c] = s / d;
+  }
+}
+
+// ---- launch helpers ------------------------------------------------------------------------------------
+template <typename Kern, typename Args>
+static void launch_persistent(Kern kern, bool &attr_set, int lds_bytes, long long ntiles, const Args &a) {
+  if (lds_bytes > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
+  const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
+  long long grid = (ntiles + FL_WAVES - 1) / FL_WAVES;
+  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FL_WAVES * 64), lds_bytes, current_stream(), a);
+}
+
+static long long tiles_of(int b, int s, int kp, int p) {
+  return (long long)b * (((long long)s * kp + 16 * p - 1) / (16 * p));
+}
+
+}  // namespace pwclo
+
+using namespace pwclo;
+
+extern "C" void upconv_fused_kernel_wrapper(int b, int n, int s, int k, const float *xyz2,
+                                            const float *xyz1, const float *feat1, const int *idx,
+                                            const float *packed_w, float *out) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k >= 1 && k <= 8, "upconv_fused: nsample=%d outside [1,8]", k);
+  UpconvArgs a{xyz2, xyz1, feat1, idx, packed_w, out, b, n, s, k};
+  static bool attr = false;
+  launch_persistent(upconv_kernel<8, 2>, attr, 4 * (layer_floats(5, 8) + layer_floats(8, 4)),
+                    tiles_of(b, s, 8, 2), a);
+  check_launch("upconv_fused");
+}
+
+extern "C" void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int c2, int w1, int w2,
+                                               const float *src0, const float *src1, const float *src2,
+                                               const float *packed_w, float *out) {
+  if (b <= 0 || s <= 0) return;
+  PointwiseArgs a{{src0, src1, src2}, packed_w, out, b, s};
+#define PW_CASE(C0, C1, C2, A1, A2)                                                                 \
+  if (c0 == C0 && c1 == C1 && c2 == C2 && w1 == A1 && w2 == A2) {                                   \
+    static bool attr = false;                                                                       \
+    constexpr int NBI = (C0 + C1 + C2) / 16;                                                        \
+    constexpr int lds = 4 * (layer_floats(NBI, A1 / 16) + (A2 > 0 ? layer_floats(A1 / 16, A2 / 16) : 0)); \
+    launch_persistent(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 2>, attr, lds,   \
+                      tiles_of(b, s, 1, 2), a);                                                     \
+    check_launch("pointwise_fused");                                                                \
+    return;                                                                                         \
+  }
+  PW_CASE(64, 64, 0, 64, 0)      // set-upconv post_mlp, level 3: [64 | 64] -> 64
+  PW_CASE(64, 32, 0, 64, 0)      // level 2
+  PW_CASE(64, 16, 0, 64, 0)      // level 1
+  PW_CASE(64, 64, 64, 128, 64)   // flow predictors, level 3: [64|64|64] -> 128 -> 64
+  PW_CASE(32, 64, 64, 128, 64)   // features predictor, level 2: [C|64|64]
+  PW_CASE(64, 64, 32, 128, 64)   // mask predictor, level 2: [64|64|C]
+  PW_CASE(16, 64, 64, 128, 64)   // features predictor, level 1
+  PW_CASE(128, 64, 0, 128, 64)   // l4_flow_predictor: [128|64] -> 128 -> 64
+#undef PW_CASE
+  set_error(PWCLO_EINVAL, "pointwise_fused: no kernel for sources (%d,%d,%d) widths (%d,%d)", c0, c1, c2,
+            w1, w2);
+}
+
+extern "C" void cv_fused_a1_kernel_wrapper(int b, int n, int s, int k, int c, const float *xyz1,
+                                           const float *feat1, const float *xyz2, const float *feat2,
+                                           const int *idx, const float *packed_w, float *pix) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a1: nsample_q=%d outside [1,32]", k);
+  CVArgs a{xyz1, feat1, xyz2, feat2, idx, packed_w, pix, nullptr, b, n, s, k};
+  const int kp = k > 16 ? 32 : (k > 8 ? 16 : 8);
+#define A1_CASE(C, KP)                                                                              \
+  if (c == C && kp == KP) {                                                                         \
+    static bool attr = false;                                                                       \
+    constexpr int lds = 4 * (layer_floats(1 + 2 * (C / 16), 8) + layer_floats(8, 4) + layer_floats(4, 4)); \
+    launch_persistent(cv_a1_kernel<C / 16, KP, 2>, attr, lds, tiles_of(b, s, KP, 2), a);            \
+    check_launch("cv_fused_a1");                                                                    \
+    return;                                                                                         \
+  }
+  A1_CASE(64, 32) A1_CASE(64, 8) A1_CASE(32, 8) A1_CASE(16, 8)
+#undef A1_CASE
+  set_error(PWCLO_EINVAL, "cv_fused_a1: no kernel for c=%d nsample_q=%d", c, k);
+}
+
+extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const float *xyz1,
+                                           const float *xyz2, const int *idx, const float *packed_w,
+                                           const float *pix, float *out) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a2: nsample_q=%d outside [1,32]", k);
+  CVArgs a{xyz1, nullptr, xyz2, nullptr, idx, packed_w, const_cast<float *>(pix), out, b, n, s, k};
+  const int kp = k > 16 ? 32 : (k > 8 ? 16 : 8);
+  constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(8, 8) + layer_floats(8, 4));
+  static bool attr32 = false, attr16 = false, attr8 = false;
+  if (kp == 32) launch_persistent(cv_a2_kernel<32, 2>, attr32, lds, tiles_of(b, s, 32, 2), a);
+  else if (kp == 16) launch_persistent(cv_a2_kernel<16, 2>, attr16, lds, tiles_of(b, s, 16, 2), a);
+  else launch_persistent(cv_a2_kernel<8, 2>, attr8, lds, tiles_of(b, s, 8, 2), a);
+  check_launch("cv_fused_a2");
+}
+
+extern "C" void cv_fused_b_kernel_wrapper(int b, int s, int k, int c, const float *xyz1,
+                                          const float *feat1, const float *first, const int *idx,
+                                          const float *packed_w, float *out) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k >= 1 && k <= 4, "cv_fused_b: nsample=%d outside [1,4]", k);
+  CVArgs a{xyz1, feat1, xyz1, first, idx, packed_w, nullptr, out, b, s, s, k};
+#define B_CASE(C)                                                                                   \
+  if (c == C) {                                                                                     \
+    static bool attr = false;                                                                       \
+    constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(8 + C / 16, 8) + layer_floats(8, 4)); \
+    launch_persistent(cv_b_kernel<C / 16, 4, 2>, attr, lds, tiles_of(b, s, 4, 2), a);               \
+    check_launch("cv_fused_b");                                                                     \
+    return;                                                                                         \
+  }
+  B_CASE(64) B_CASE(32) B_CASE(16)
+#undef B_CASE
+  set_error(PWCLO_EINVAL, "cv_fused_b: no kernel for c=%d", c);
+}
+
+extern "C" void masked_pool_kernel_wrapper(int b, int n, const float *emb, const float *mask, float *out) {
+  if (b <= 0 || n <= 0) return;
+  hipLaunchKernelGGL(masked_pool_kernel, dim3(b), dim3(64 * MP_PARTS), 0, current_stream(), n, emb, mask, out);
+  check_launch("masked_pool");
+}

@@ -1,0 +1,119 @@
+// Register-resident per-point MLP on the fp32 matrix cores (gfx950, v_mfma_f32_16x16x4_f32).
+//
+// The grouped "shared MLPs" of PWCLO-Net (P2/pytorch_utils.py:52-83: Conv2d 1x1 -> BN -> ReLU
+// over (B,C,S,K)) are dense contractions over channels at every (query, neighbour) "pixel":
+//     D[cout][pixel] = sum_cin W[cout][cin] * X[cin][pixel] + bias[cout]
+// One wave owns P blocks of 16 pixels and walks them through ALL layers of a stack without
+// leaving registers:
+//   * MFMA roles: A = W (16 couts x 4 cins), B = X (4 cins x 16 pixels), so a lane (g = lane>>4,
+//     j = lane&15) holds pixel j and, in every block of 16 channels, the four channels
+//     16m+4g+r (r = 0..3) -- the accumulator layout of the 16x16 MFMA (row = 4g+r, col = j).
+//   * The k-steps of the next layer are enumerated as (m, r) and use channel 16m+4g+r from lane
+//     group g, so a layer's accumulators ARE the next layer's B operands: no LDS round trip and
+//     no cross-lane movement between layers.  The matching permutation lives in the packed
+//     weights (host side, fused.py: pack_layer).
+//   * BatchNorm (eval) is folded into W and bias on the host; bias seeds the accumulator.
+//   * Packed weights are staged once per workgroup into LDS ([o][m][lane][4] floats: one
+//     conflict-free ds_read_b128 per (o, m) and lane feeds 4*P MFMAs) and stay resident while
+//     the (persistent) workgroup streams pixel tiles; there is no barrier after the fill.
+// fp32 MFMA is bit-for-bit an fmaf chain in k order, so results differ from a CPU GEMM only by
+// summation order (parity bound 1e-5, tests/test_gpu_fused.py).
+#pragma once
+#include "common.hpp"
+
+namespace pwclo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Floats occupied in LDS by one packed layer: NBO*NBI 1-KiB operand tiles + NBO*16 biases.
+constexpr int layer_floats(int nbi, int nbo) { return nbo * nbi * 256 + nbo * 16; }
+
+// Cooperative copy of `nfloats` (multiple of 4) packed floats from global memory into LDS.
+__device__ __forceinline__ void stage_weights(float *lds, const float *__restrict__ g, int nfloats) {
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(g);
+  f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+  for (int i = threadIdx.x; i < nfloats / 4; i += blockDim.x) dst[i] = src[i];
+}
+
+// One layer for P pixel blocks.  `w` points at the layer's packed weights in LDS.
+template <int NBI, int NBO, int P, bool RELU>
+__device__ __forceinline__ void mlp_layer(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
+                                          const float *w, int lane) {
+  const int g = lane >> 4;
+  const float *bias = w + NBO * NBI * 256;
+#pragma unroll
+  for (int o = 0; o < NBO; ++o) {
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 16 * o + 4 * g);
+    f32x4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = bv;
+#pragma unroll
+    for (int m = 0; m < NBI; ++m) {
+      const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + ((o * NBI + m) * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[r], in[m][p][r], acc[p], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (RELU) {
+        f32x4 v = acc[p];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        out[o][p] = v;
+      } else {
+        out[o][p] = acc[p];
+      }
+    }
+    // Keep the unrolled output blocks in program order: without this the scheduler hoists the
+    // LDS operand reads of every later block (4 VGPRs each) and spills.
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- reductions over the K neighbours of a query ------------------------------------------------
+// Pixels are ordered (query, k) with k fastest and K padded to KP in {1, 4, 8, 16, 32}; inside a
+// 16-pixel block the neighbours of one query are KP (<= 16) consecutive lanes of a DPP row.
+// GROUP = min(KP, 16).  After the call every lane of a group holds the group's result.
+template <int GROUP, typename Op>
+__device__ __forceinline__ unsigned group_allreduce_u32(unsigned v, Op op) {
+  if (GROUP >= 2) v = op(v, dpp_u32<0xB1>(v));    // xor 1
+  if (GROUP >= 4) v = op(v, dpp_u32<0x4E>(v));    // xor 2
+  if (GROUP >= 8) v = op(v, dpp_u32<0x141>(v));   // mirror within 8
+  if (GROUP >= 16) v = op(v, dpp_u32<0x140>(v));  // mirror within 16
+  return v;
+}
+
+struct OpAddF32 {
+  __device__ __forceinline__ unsigned operator()(unsigned a, unsigned b) const {
+    return __float_as_uint(__uint_as_float(a) + __uint_as_float(b));
+  }
+};
+struct OpMaxF32Bits {  // max of floats through their bit patterns: valid for non-negative values,
+  __device__ __forceinline__ unsigned operator()(unsigned a, unsigned b) const {  // -inf sorts low
+    return (int)a > (int)b ? a : b;
+  }
+};
+
+template <int GROUP>
+__device__ __forceinline__ float group_sum(float v) {
+  return __uint_as_float(group_allreduce_u32<GROUP>(__float_as_uint(v), OpAddF32()));
+}
+
+// max for values that are >= +0 (post-ReLU) or the sentinel -inf (bit pattern 0xff800000 < 0).
+template <int GROUP>
+__device__ __forceinline__ float group_max_nonneg(float v) {
+  return __uint_as_float(group_allreduce_u32<GROUP>(__float_as_uint(v), OpMaxF32Bits()));
+}
+
+// ---- pixel bookkeeping --------------------------------------------------------------------------
+// pixel index -> (query s, neighbour slot k); KP is a power of two.
+template <int KP>
+struct PixelMap {
+  int s, k;
+  __device__ __forceinline__ PixelMap(int pix) : s(pix / KP), k(pix % KP) {}
+};
+
+}  // namespace pwclo

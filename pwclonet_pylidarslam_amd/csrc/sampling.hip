@@ -49,7 +49,8 @@ __device__ __forceinline__ unsigned fps_bitrev(unsigned v, int bits) {
 template <int T, int E, int I, bool LDS_TABLE>
 __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int log2bs,
                                                     const float *__restrict__ dataset,
-                                                    int *__restrict__ idxs) {
+                                                    int *__restrict__ idxs,
+                                                    float *__restrict__ new_xyz) {
   constexpr int PPT = I << E;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [3] rotating
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
   constexpr int NW = T / 64;
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   int *out = idxs + (size_t)blockIdx.x * m;
+  float *oxyz = new_xyz ? new_xyz + (size_t)blockIdx.x * m * 3 : nullptr;  // optional (b,m,3) samples
   const int kstride = E == 0 ? T : bs;  // distance between consecutive points of one residue
 
   float x[PPT], y[PPT], z[PPT];
@@ -99,6 +101,9 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
     } else {
       x1 = pts[old * 3 + 0]; y1 = pts[old * 3 + 1]; z1 = pts[old * 3 + 2];
     }
+    if (oxyz && tid == 0) {  // coordinates of sample it-1 (gather_operation fused into the sampler)
+      oxyz[(it - 1) * 3 + 0] = x1; oxyz[(it - 1) * 3 + 1] = y1; oxyz[(it - 1) * 3 + 2] = z1;
+    }
     int best = __float_as_int(-1.0f);
     int bestj = 0;
 #pragma unroll
@@ -134,6 +139,11 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
     }
     if (tid == 0) out[it] = old;
   }
+  if (oxyz && tid == 0) {
+    oxyz[(m - 1) * 3 + 0] = pts[old * 3 + 0];
+    oxyz[(m - 1) * 3 + 1] = pts[old * 3 + 1];
+    oxyz[(m - 1) * 3 + 2] = pts[old * 3 + 2];
+  }
 }
 
 // Fallback for clouds too large for the register file: same selection rule, running distances in
@@ -142,18 +152,23 @@ template <int T>
 __global__ __launch_bounds__(T) void fps_stream_kernel(int n, int m, int bs, int log2bs,
                                                        const float *__restrict__ dataset,
                                                        float *__restrict__ temp,
-                                                       int *__restrict__ idxs) {
+                                                       int *__restrict__ idxs,
+                                                       float *__restrict__ new_xyz) {
   __shared__ unsigned long long slots[2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = T / 64;
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   float *tmp = temp + (size_t)blockIdx.x * n;
   int *out = idxs + (size_t)blockIdx.x * m;
+  float *oxyz = new_xyz ? new_xyz + (size_t)blockIdx.x * m * 3 : nullptr;
   const unsigned rev = fps_bitrev((unsigned)(tid & (bs - 1)), log2bs) << PRI_SHIFT;
   if (tid == 0) out[0] = 0;
   int old = 0;
   for (int it = 1; it < m; ++it) {
     const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+    if (oxyz && tid == 0) {
+      oxyz[(it - 1) * 3 + 0] = x1; oxyz[(it - 1) * 3 + 1] = y1; oxyz[(it - 1) * 3 + 2] = z1;
+    }
     float best = -1.0f;
     unsigned bestpri = 0xFFFFFFFFu;
     for (int k = tid; k < n; k += T) {
@@ -191,10 +206,16 @@ __global__ __launch_bounds__(T) void fps_stream_kernel(int n, int m, int bs, int
     }
     if (tid == 0) out[it] = old;
   }
+  if (oxyz && tid == 0) {
+    oxyz[(m - 1) * 3 + 0] = pts[old * 3 + 0];
+    oxyz[(m - 1) * 3 + 1] = pts[old * 3 + 1];
+    oxyz[(m - 1) * 3 + 2] = pts[old * 3 + 2];
+  }
 }
 
 template <int T, int E, int I>
-static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float *dataset, int *idxs) {
+static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float *dataset, int *idxs,
+                           float *new_xyz) {
   const size_t table_bytes = FPS_SLOT_BYTES + (size_t)n * sizeof(float4);
   hipStream_t st = current_stream();
   if (table_bytes <= 160 * 1024) {
@@ -205,10 +226,10 @@ static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float 
                                 160 * 1024);
       big_lds_enabled = true;
     }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(T), table_bytes, st, n, m, bs, log2bs, dataset, idxs);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(T), table_bytes, st, n, m, bs, log2bs, dataset, idxs, new_xyz);
   } else {
     hipLaunchKernelGGL((fps_reg_kernel<T, E, I, false>), dim3(b), dim3(T), FPS_SLOT_BYTES, st, n, m,
-                       bs, log2bs, dataset, idxs);
+                       bs, log2bs, dataset, idxs, new_xyz);
   }
 }
 
@@ -257,8 +278,8 @@ __global__ __launch_bounds__(256) void gather_points_grad_kernel(int c, int n, i
 
 using namespace pwclo;
 
-extern "C" void furthest_point_sampling_kernel_wrapper(int b, int n, int m, const float *dataset,
-                                                       float *temp, int *idxs) {
+static void fps_dispatch(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+                         float *new_xyz) {
   if (b <= 0 || m <= 0) return;
   PWCLO_REQUIRE(n >= 1, "furthest_point_sampling: n=%d must be >= 1", n);
   PWCLO_REQUIRE((long long)n < (1ll << PRI_SHIFT) * 1ll, "furthest_point_sampling: n=%d too large", n);
@@ -272,7 +293,7 @@ extern "C" void furthest_point_sampling_kernel_wrapper(int b, int n, int m, cons
   if (T == 1024 && I > 16) { T = 512; E = 0; I = ceil_div(n, 512); }   // VGPR budget at 16 waves
 #define FPS_CASE(TT, EE, II)                                               \
   if (T == TT && E == EE && I <= II) {                                     \
-    launch_fps_reg<TT, EE, II>(b, n, m, bs, log2bs, dataset, idxs);       \
+    launch_fps_reg<TT, EE, II>(b, n, m, bs, log2bs, dataset, idxs, new_xyz);       \
     check_launch("furthest_point_sampling");                              \
     return;                                                                \
   }
@@ -292,15 +313,25 @@ extern "C" void furthest_point_sampling_kernel_wrapper(int b, int n, int m, cons
                  FPS_CASE(64, 3, 1) FPS_CASE(64, 3, 2) FPS_CASE(64, 3, 4) FPS_CASE(64, 3, 8) }
 #undef FPS_CASE
   if (n <= 24576) {  // register-resident fallback (large clouds, or a forced T without a case)
-    launch_fps_reg<512, 0, 48>(b, n, m, bs, log2bs, dataset, idxs);
+    launch_fps_reg<512, 0, 48>(b, n, m, bs, log2bs, dataset, idxs, new_xyz);
     check_launch("furthest_point_sampling");
     return;
   }
   PWCLO_REQUIRE(temp != nullptr,
                 "furthest_point_sampling: n=%d needs the (b,n) temp buffer pre-filled with 1e10", n);
   hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, current_stream(), n, m, bs,
-                     log2bs, dataset, temp, idxs);
+                     log2bs, dataset, temp, idxs, new_xyz);
   check_launch("furthest_point_sampling(stream)");
+}
+
+extern "C" void furthest_point_sampling_kernel_wrapper(int b, int n, int m, const float *dataset,
+                                                       float *temp, int *idxs) {
+  fps_dispatch(b, n, m, dataset, temp, idxs, nullptr);
+}
+
+extern "C" void furthest_point_sampling_xyz_kernel_wrapper(int b, int n, int m, const float *dataset,
+                                                           float *temp, int *idxs, float *new_xyz) {
+  fps_dispatch(b, n, m, dataset, temp, idxs, new_xyz);
 }
 
 extern "C" void gather_points_kernel_wrapper(int b, int c, int n, int npoints, const float *points,

@@ -20,6 +20,7 @@ __device__ __forceinline__ quat hamilton(const quat a, const quat b) {
   return r;
 }
 
+template <bool POINT_MAJOR>
 __global__ __launch_bounds__(256) void quat_warp_kernel(int n, const float *__restrict__ xyz,
                                                         const float *__restrict__ q,
                                                         const float *__restrict__ t,
@@ -32,12 +33,13 @@ __global__ __launch_bounds__(256) void quat_warp_kernel(int n, const float *__re
   const float q2 = (((qq.w * qq.w + qq.x * qq.x) + qq.y * qq.y) + qq.z * qq.z) + 1e-10f;
   const quat qi = {qq.w / q2, (qq.x * -1.0f) / q2, (qq.y * -1.0f) / q2, (qq.z * -1.0f) / q2};
   const float *src = xyz + (size_t)b * 3 * n;
-  const quat p = {0.0f, src[j], src[n + j], src[2 * n + j]};
+  const int sx = POINT_MAJOR ? 3 * j : j, st = POINT_MAJOR ? 1 : n;  // (b,n,3) or (b,3,n)
+  const quat p = {0.0f, src[sx], src[sx + st], src[sx + 2 * st]};
   const quat r = hamilton(hamilton(qq, p), qi);
   float *dst = out + (size_t)b * 3 * n;
-  dst[j] = r.x + t[b * 3 + 0];
-  dst[n + j] = r.y + t[b * 3 + 1];
-  dst[2 * n + j] = r.z + t[b * 3 + 2];
+  dst[sx] = r.x + t[b * 3 + 0];
+  dst[sx + st] = r.y + t[b * 3 + 1];
+  dst[sx + 2 * st] = r.z + t[b * 3 + 2];
 }
 
 }  // namespace pwclo
@@ -48,7 +50,17 @@ extern "C" void quat_warp_kernel_wrapper(int b, int n, const float *xyz, const f
                                          const float *t, float *out) {
   if (b <= 0 || n <= 0) return;
   PWCLO_REQUIRE(b <= 65535, "quat_warp: b=%d exceeds the grid limit", b);
-  hipLaunchKernelGGL(quat_warp_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, current_stream(), n,
-                     xyz, q, t, out);
+  hipLaunchKernelGGL(quat_warp_kernel<false>, dim3(ceil_div(n, 256), b), dim3(256), 0, current_stream(),
+                     n, xyz, q, t, out);
   check_launch("quat_warp");
+}
+
+// Same transform on point-major (b,n,3) clouds (layout of the fused eval-mode pipeline).
+extern "C" void quat_warp_pm_kernel_wrapper(int b, int n, const float *xyz, const float *q,
+                                            const float *t, float *out) {
+  if (b <= 0 || n <= 0) return;
+  PWCLO_REQUIRE(b <= 65535, "quat_warp_pm: b=%d exceeds the grid limit", b);
+  hipLaunchKernelGGL(quat_warp_kernel<true>, dim3(ceil_div(n, 256), b), dim3(256), 0, current_stream(),
+                     n, xyz, q, t, out);
+  check_launch("quat_warp_pm");
 }

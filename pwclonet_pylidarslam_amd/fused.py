@@ -1,0 +1,348 @@
+"""Host side of the fused eval-mode kernels: BatchNorm folding, weight packing, launch wrappers.
+
+Kernels (csrc/fused_*.hip) keep feature tensors point-major ``(B, N, C)`` and take every layer
+as one packed buffer (see csrc/mlp_core.hpp):
+    [NBO][NBI][64 lanes][4]  with  Wp[o][m][lane][r] = W'[16*o + lane%16][phys(16*m + 4*(lane//16) + r)]
+    followed by NBO*16 bias values,
+where ``W' = W * gamma/sqrt(var+eps)``, ``bias' = beta - mean*gamma/sqrt(var+eps)`` (eval-mode
+BatchNorm folded into the 1x1 convolution) and ``phys`` maps the kernel's physical input
+channel order (16-channel blocks, one source per block) to the layer's original input channels.
+"""
+import torch
+
+from . import _lib
+
+
+def fold_conv_bn(layer):
+    """``layer``: one SharedMLP entry (pytorch_utils._ConvBlock with conv [+ bn] [+ relu]).
+    Returns (W (Cout,Cin), bias (Cout,)) of the equivalent affine map in eval mode."""
+    conv = layer.conv
+    w = conv.weight.detach().reshape(conv.weight.shape[0], -1).double()
+    b = conv.bias.detach().double() if conv.bias is not None else torch.zeros(w.shape[0], dtype=torch.float64,
+                                                                             device=w.device)
+    if hasattr(layer, "bn"):
+        bn = layer.bn.bn
+        s = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        w = w * s[:, None]
+        b = (b - bn.running_mean.detach().double()) * s + bn.bias.detach().double()
+    return w.float(), b.float()
+
+
+def pack_layer(w, b, phys_map, nbo=None):
+    """Pack one folded layer.  ``phys_map``: for every physical input channel (length multiple of
+    16) the original input channel, or -1 for padding.  Output channels are padded to 16*nbo."""
+    cout, _ = w.shape
+    nbi = len(phys_map) // 16
+    assert len(phys_map) == 16 * nbi
+    nbo = nbo or (cout + 15) // 16
+    pm = torch.as_tensor(phys_map, dtype=torch.long, device=w.device)
+    wphys = torch.zeros((16 * nbo, 16 * nbi), dtype=torch.float32, device=w.device)
+    valid = pm >= 0
+    wphys[:cout, valid] = w[:, pm[valid]]
+    # (o,row,m,g,r) -> (o,m,g,row,r): lane = 16*g + row
+    wp = wphys.view(nbo, 16, nbi, 4, 4).permute(0, 2, 3, 1, 4).reshape(-1)
+    bias = torch.zeros(16 * nbo, dtype=torch.float32, device=w.device)
+    bias[:cout] = b
+    return torch.cat((wp, bias)).contiguous()
+
+
+def chain_map(cout_prev, nb):
+    """Physical->original map of a layer fed by the previous layer's (padded) output."""
+    return [c if c < cout_prev else -1 for c in range(16 * nb)]
+
+
+def pack_stack(shared_mlp, first_map):
+    """Pack every layer of a SharedMLP whose first layer reads the physical order `first_map`.
+    Returns (packed float tensor, [padded widths])."""
+    parts, widths = [], []
+    pm = first_map
+    for layer in shared_mlp:
+        w, b = fold_conv_bn(layer)
+        nbo = (w.shape[0] + 15) // 16
+        parts.append(pack_layer(w, b, pm, nbo))
+        widths.append(16 * nbo)
+        pm = chain_map(w.shape[0], nbo)
+    return torch.cat(parts).contiguous(), widths
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else 0
+
+
+# ---- set abstraction -------------------------------------------------------------------------------
+
+def sa_first_map(c_feat):
+    """Physical input order of csrc/fused_sa.hip: block 0 = [dx,dy,dz(,qx,qy,qz)], then features.
+    Original order (pointnet2_modules.py:222 / :233): [xyz_diff(3), features(C)] or
+    [xyz_diff(3), grouped_xyz(3)]."""
+    if c_feat == 0:
+        return [0, 1, 2, 3, 4, 5] + [-1] * 10
+    return [0, 1, 2] + [-1] * 13 + [3 + c for c in range(c_feat)]
+
+
+class FusedSA:
+    """Packed eval-mode weights of one ``PointnetSAModulePWCLONet`` + launcher."""
+
+    def __init__(self, module):
+        convs = list(module.mlp_module)
+        cin = convs[0].conv.weight.shape[1]
+        self.c_feat = cin - 3 if cin != 6 else 0
+        assert self.c_feat % 16 == 0
+        self.packed, self.widths = pack_stack(module.mlp_module, sa_first_map(self.c_feat))
+        self.c_out = convs[-1].conv.weight.shape[0]
+        assert self.c_out == self.widths[-1], "last layer width must be a multiple of 16"
+        self.nsample = module.nsample
+
+    def __call__(self, xyz, new_xyz, feat_pm, idx):
+        """xyz (B,N,3), new_xyz (B,S,3), feat_pm (B,N,C) point-major or None, idx (B,S,K) int32
+        -> (B,S,Cout) point-major."""
+        B, N, _ = xyz.shape
+        S, K = idx.shape[1], idx.shape[2]
+        out = torch.empty((B, S, self.c_out), dtype=torch.float32, device=xyz.device)
+        _lib.call("sa_fused_kernel_wrapper", xyz.device, B, N, S, K, self.c_feat, *self.widths,
+                  _p(xyz), _p(new_xyz), _p(feat_pm), _p(idx), _p(self.packed), _p(out))
+        return out
+
+
+# ---- FPS + sampled coordinates, point-major warp -------------------------------------------------------
+
+def fps_with_xyz(xyz, npoint):
+    """xyz (B,N,3) -> (idx (B,npoint) int32, new_xyz (B,npoint,3)): FPS with the following
+    gather_operation folded into the sampler."""
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
+    tmp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device) if N > 24576 else None
+    _lib.call("furthest_point_sampling_xyz_kernel_wrapper", xyz.device, B, N, npoint, _p(xyz), _p(tmp),
+              _p(idx), _p(new_xyz))
+    return idx, new_xyz
+
+
+def quat_warp_pm(xyz, q, t):
+    """xyz (B,N,3) point-major, q (B,4), t (B,3) -> (B,N,3)."""
+    B, N, _ = xyz.shape
+    q = q.reshape(B, 4).contiguous()
+    t = t.reshape(B, 3).contiguous()
+    out = torch.empty_like(xyz)
+    _lib.call("quat_warp_pm_kernel_wrapper", xyz.device, B, N, _p(xyz), _p(q), _p(t), _p(out))
+    return out
+
+
+def knn(nsample, xyz, new_xyz):
+    from .pointnet2_ops import _ext
+    return _ext.knn_point(nsample, xyz, new_xyz)
+
+
+# ---- point-wise MLP over concatenated sources ----------------------------------------------------------
+
+class FusedPointwise:
+    """SharedMLP (1 or 2 layers) over cat(sources, dim=channels); sources point-major (B,S,Ci)."""
+
+    def __init__(self, shared_mlp, source_channels):
+        self.src_c = list(source_channels) + [0] * (3 - len(source_channels))
+        cin = sum(source_channels)
+        assert all(c % 16 == 0 for c in source_channels)
+        assert list(shared_mlp)[0].conv.weight.shape[1] == cin
+        self.packed, widths = pack_stack(shared_mlp, list(range(cin)))
+        assert len(widths) in (1, 2)
+        self.w1, self.w2 = widths[0], (widths[1] if len(widths) == 2 else 0)
+        self.c_out = widths[-1]
+
+    def __call__(self, *sources):
+        B, S, _ = sources[0].shape
+        src = list(sources) + [None] * (3 - len(sources))
+        out = torch.empty((B, S, self.c_out), dtype=torch.float32, device=sources[0].device)
+        _lib.call("pointwise_fused_kernel_wrapper", out.device, B, S, *self.src_c, self.w1, self.w2,
+                  _p(src[0]), _p(src[1]), _p(src[2]), _p(self.packed), _p(out))
+        return out
+
+
+# ---- set-upconv ----------------------------------------------------------------------------------------
+
+class FusedUpconv:
+    """``PointnetFPModulePWCLONet`` (knn=True, nsample<=8, 64-channel coarse features)."""
+
+    def __init__(self, module):
+        assert module.knn and module.use_xyz
+        c1 = list(module.mlp)[0].conv.weight.shape[1] - 3
+        assert c1 == 64, "set-upconv kernel is built for 64-channel coarse features"
+        # original order (pointnet2_modules.py:490): [grouped feat (64), xyz_diff (3)]
+        first = list(range(64)) + [64, 65, 66] + [-1] * 13
+        self.packed, widths = pack_stack(module.mlp, first)
+        assert widths == [128, 64]
+        c2 = list(module.post_mlp)[0].conv.weight.shape[1] - 64
+        self.post = FusedPointwise(module.post_mlp, [64, c2])
+        self.nsample = module.nsample
+
+    def pooled(self, xyz2, xyz1, feat1, idx):
+        B, S, _ = xyz2.shape
+        N = xyz1.shape[1]
+        out = torch.empty((B, S, 64), dtype=torch.float32, device=xyz2.device)
+        _lib.call("upconv_fused_kernel_wrapper", xyz2.device, B, N, S, idx.shape[2], _p(xyz2), _p(xyz1),
+                  _p(feat1), _p(idx), _p(self.packed), _p(out))
+        return out
+
+    def __call__(self, xyz2, xyz1, feat2, feat1, idx):
+        """xyz2 (B,S,3) fine, xyz1 (B,N,3) coarse, feat2 (B,S,C2), feat1 (B,N,64), idx (B,S,K)
+        = knn(K, xyz1, xyz2) -> (B,S,64)."""
+        return self.post(self.pooled(xyz2, xyz1, feat1, idx), feat2)
+
+
+# ---- attentive cost volume -----------------------------------------------------------------------------
+
+class FusedCostVolume:
+    """``CostVolume`` with in_channel1 == in_channel2 in {16,32,64}, mlp1=[128,64,64], mlp2=[128,64]."""
+
+    def __init__(self, module):
+        c1, c2, _ = module.in_channel
+        assert c1 == c2 and c1 in (16, 32, 64)
+        self.c = c1
+        self.nsample, self.nsample_q = module.nsample, module.nsample_q
+        geo = list(range(10)) + [-1] * 6
+        # mlp_convs input (costvolume.py:105-110): [geometry10, feat1 (C), feat2 gathered (C)]
+        self.w_a1, w = pack_stack(module.mlp_convs, geo + [10 + c for c in range(2 * c1)])
+        assert w == [128, 64, 64]
+        wx1, wd = pack_stack(module.mlp_conv_xyz_1, geo)
+        w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)))     # [enc (64) | feat (64)], :133
+        assert wd == [64] and wd2 == [128, 64]
+        self.w_a2 = torch.cat((wx1, w2)).contiguous()
+        wx2, _ = pack_stack(module.mlp_conv_xyz_2, geo)
+        w3, wd3 = pack_stack(module.mlp3_convs, list(range(128 + c1)))  # [enc2 | feat1 | first], :176
+        assert wd3 == [128, 64]
+        self.w_b = torch.cat((wx2, w3)).contiguous()
+
+    def __call__(self, xyz1, feat1, xyz2, feat2, idx_q=None, idx=None):
+        """xyz1 (B,S,3) (warped) frame-1 points, feat1 (B,S,C), xyz2 (B,N,3), feat2 (B,N,C),
+        all point-major -> (B,S,64)."""
+        B, S, _ = xyz1.shape
+        N = xyz2.shape[1]
+        dev = xyz1.device
+        kq, k = self.nsample_q, self.nsample
+        if idx_q is None:
+            idx_q = knn(kq, xyz2, xyz1)
+        kp = 32 if kq > 16 else (16 if kq > 8 else 8)
+        pix = torch.empty((B, S * kp, 64), dtype=torch.float32, device=dev)
+        _lib.call("cv_fused_a1_kernel_wrapper", dev, B, N, S, kq, self.c, _p(xyz1), _p(feat1), _p(xyz2),
+                  _p(feat2), _p(idx_q), _p(self.w_a1), _p(pix))
+        first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
+        _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
+                  _p(self.w_a2), _p(pix), _p(first))
+        if idx is None:
+            idx = knn(k, xyz1, xyz1)
+        out = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
+        _lib.call("cv_fused_b_kernel_wrapper", dev, B, S, k, self.c, _p(xyz1), _p(feat1), _p(first),
+                  _p(idx), _p(self.w_b), _p(out))
+        return out
+
+
+def masked_pool(emb, mask):
+    """emb, mask (B,N,64) point-major -> (B,64) = sum_n emb * softmax_n(mask)."""
+    B, N, C = emb.shape
+    assert C == 64 and mask.shape == emb.shape
+    out = torch.empty((B, 64), dtype=torch.float32, device=emb.device)
+    _lib.call("masked_pool_kernel_wrapper", emb.device, B, N, _p(emb), _p(mask), _p(out))
+    return out
+
+
+class FusedPoseHead:
+    """``PoseCalculator`` after the pooling: 64 -> 256 -> (q 4, t 3), eval mode (no dropout)."""
+
+    def __init__(self, module):
+        g = lambda blk: (blk.conv.weight.detach().squeeze(-1), blk.conv.bias.detach())
+        self.w_qt, self.b_qt = g(module.conv1d_q_t)
+        self.w_q, self.b_q = g(module.conv1d_q)
+        self.w_t, self.b_t = g(module.conv1d_t)
+
+    def __call__(self, emb, mask):
+        pooled = masked_pool(emb, mask)                                   # (B,64)
+        big = torch.nn.functional.linear(pooled, self.w_qt, self.b_qt)    # (B,256)
+        q = torch.nn.functional.linear(big, self.w_q, self.b_q)
+        q = q / (torch.sqrt(torch.sum(q * q, dim=1, keepdim=True) + 1e-10) + 1e-10)
+        t = torch.nn.functional.linear(big, self.w_t, self.b_t)
+        return q, t                                                       # (B,4), (B,3)
+
+
+# ---- whole network --------------------------------------------------------------------------------------
+
+class FusedPWCLONet:
+    """Eval-mode forward of a ``PWCLONet`` on the fused kernels (point-major activations).
+
+    Built from (and sharing nothing mutable with) an existing module: weights are folded and
+    packed once; call again after loading a new ``state_dict``.  The siamese pyramid runs both
+    frames as one batch, the level-4 FPS of ``flow_feature_encoding`` reuses ``psa_4``'s (same
+    cloud, same result: SURVEY.md appendix B) and the two set-upconvs of a level share one
+    neighbour search (identical inputs)."""
+
+    def __init__(self, net):
+        from .pwclonet import PWCLO_utils as pw
+        assert not net.training, "the fused path implements eval-mode semantics"
+        self.pw = pw
+        self.sa = [FusedSA(m) for m in (net.psa_1, net.psa_2, net.psa_3, net.psa_4)]
+        self.sa_cfg = [(m.npoint, m.nsample) for m in (net.psa_1, net.psa_2, net.psa_3, net.psa_4)]
+        self.cv3 = FusedCostVolume(net.cost_volume)
+        self.ffe = FusedSA(net.flow_feature_encoding)
+        self.ffe_cfg = (net.flow_feature_encoding.npoint, net.flow_feature_encoding.nsample)
+        self.l4_pred = FusedPointwise(net.l4_flow_predictor.mlp_convs, [128, 64])
+        self.l4_head = FusedPoseHead(net.pose_calculator_4)
+        self.pwr = []
+        for lvl, m in ((3, net.pose_warp_refinement_3), (2, net.pose_warp_refinement_2),
+                       (1, net.pose_warp_refinement_1)):
+            c = m.in_channel[0]
+            d = dict(up_f=FusedUpconv(m.setupconv_features), up_m=FusedUpconv(m.setupconv_mask),
+                     cv=FusedCostVolume(m.cost_volume),
+                     pred_f=FusedPointwise(m.flow_predictor_features.mlp_convs, [c, 64, 64]),
+                     pred_m=None if m.last_pose_estimation else
+                     FusedPointwise(m.flow_predictor_mask.mlp_convs, [64, 64, c]),
+                     head=FusedPoseHead(m.pose_calculator), last=m.last_pose_estimation)
+            self.pwr.append(d)
+
+    def _refine(self, d, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev):
+        pw = self.pw
+        B = x1.shape[0]
+        idx_up = knn(8, x1_prev, x1)
+        up_feat = d["up_f"](x1, x1_prev, f1, emb_prev, idx_up)
+        up_mask = d["up_m"](x1, x1_prev, f1, mask_prev, idx_up)
+        warped = quat_warp_pm(x1, q_prev, t_prev)
+        resid = d["cv"](warped, f1, x2, f2)
+        emb = d["pred_f"](f1, resid, up_feat)
+        mask = up_mask if d["last"] else d["pred_m"](up_mask, emb, f1)
+        q_det, t_det = d["head"](emb, mask)
+        q_c, t_c = q_prev.reshape(B, 4, 1), t_prev.reshape(B, 3, 1)
+        q = pw.mul_point_q(q_det.reshape(B, 4, 1), q_c).squeeze(2)              # pose_warp_refinement.py:139
+        t = pw.warp(t_c, q_det.reshape(B, 4, 1), t_det.reshape(B, 3, 1)).squeeze(2)   # :148
+        return q, t, emb, mask
+
+    @torch.no_grad()
+    def __call__(self, xyz_f1, xyz_f2, return_intermediates=False):
+        """xyz_f1, xyz_f2 (B,3,N) -> pose_params (B,4,7) [+ dict of point-major intermediates]."""
+        B = xyz_f1.shape[0]
+        x = torch.cat((xyz_f1, xyz_f2), dim=0).permute(0, 2, 1).contiguous()     # (2B,N,3)
+        f = None
+        lv = []
+        for fsa, (npoint, nsample) in zip(self.sa, self.sa_cfg):
+            _, new_x = fps_with_xyz(x, npoint)
+            idx = knn(nsample, x, new_x)
+            f = fsa(x, new_x, f, idx)
+            x = new_x
+            lv.append((x, f))
+        (x11, f11), (x12, f12), (x13, f13), (x14, f14) = [(a[:B], b[:B]) for a, b in lv]
+        (x21, f21), (x22, f22), (x23, f23), _ = [(a[B:], b[B:]) for a, b in lv]
+
+        flow = self.cv3(x13, f13, x23, f23)
+        # flow_feature_encoding samples the same cloud as psa_4(frame 1): reuse x14
+        emb4 = self.ffe(x13, x14, flow, knn(self.ffe_cfg[1], x13, x14))
+        mask4 = self.l4_pred(f14, emb4)
+        q4, t4 = self.l4_head(emb4, mask4)
+
+        q3, t3, emb3, mask3 = self._refine(self.pwr[0], x13, f13, x23, f23, x14, emb4, mask4, q4, t4)
+        q2, t2, emb2, mask2 = self._refine(self.pwr[1], x12, f12, x22, f22, x13, emb3, mask3, q3, t3)
+        q1, t1, emb1, mask1 = self._refine(self.pwr[2], x11, f11, x21, f21, x12, emb2, mask2, q2, t2)
+
+        unit = lambda q: q / (torch.sqrt(torch.sum(q * q, dim=-1, keepdim=True) + 1e-10) + 1e-10)
+        rows = [torch.cat((t, unit(q)), dim=-1).reshape(-1, 1, 7)
+                for q, t in ((q1, t1), (q2, t2), (q3, t3), (q4, t4))]
+        pose = torch.cat(rows, dim=1)
+        if return_intermediates:
+            return pose, dict(x11=x11, f11=f11, f13=f13, flow=flow, emb4=emb4, mask4=mask4, emb3=emb3,
+                              mask3=mask3, emb1=emb1, mask1=mask1, q=(q1, q2, q3, q4), t=(t1, t2, t3, t4))
+        return pose

@@ -1,0 +1,165 @@
+"""GPU parity of the fused eval-mode kernels (MFMA MLP stacks) against the CPU oracle.
+
+Same inputs on both sides (neighbour lists come from the oracle), mixed bound
+|a-b| <= 1e-5*|b| + 1e-5*max|b| as in test_gpu_model.py: the kernels fold BatchNorm into the
+weights and sum channels in MFMA k-order, so only the fp32 summation order differs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as M
+from oracle import ops as O
+from oracle import params
+from pwclonet_pylidarslam_amd import fused
+from pwclonet_pylidarslam_amd.pointnet2_ops.pointnet2_modules import PointnetSAModulePWCLONet
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rel=1e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    bound = rel * b.abs() + rel * b.abs().max()
+    bad = (a - b).abs() > bound
+    assert not bad.any(), "max abs err %.3e (scale %.3e), %d/%d outside bound" % (
+        (a - b).abs().max().item(), b.abs().max().item(), int(bad.sum()), bad.numel())
+
+
+def filled(module, prefix):
+    sd = module.state_dict()
+    for k, v in sd.items():
+        val = torch.from_numpy(np.array(params.fill_value(prefix + "." + k, v.shape))).reshape(v.shape)
+        v.copy_(val.to(v.dtype))
+    return module.eval(), {prefix + "." + k: v.clone() for k, v in sd.items()}
+
+
+def cloud(seed, b, n, scale=10.0):
+    gen = torch.Generator().manual_seed(seed)
+    return (torch.rand(b, n, 3, generator=gen) * 2 - 1) * scale
+
+
+@pytest.mark.parametrize("name,mlp,npoint,nsample,n,c", [
+    ("psa_1", [0, 8, 8, 16], 512, 32, 2048, 0), ("psa_2", [16, 16, 16, 32], 256, 32, 512, 16),
+    ("psa_3", [32, 32, 32, 64], 64, 16, 256, 32), ("psa_4", [64, 64, 64, 128], 16, 16, 64, 64),
+    ("flow_feature_encoding", [64, 128, 64, 64], 64, 16, 256, 64),
+    ("psa_3", [32, 32, 32, 64], 37, 11, 301, 32)])     # ragged: K < KP, S*KP not a tile multiple
+def test_fused_set_abstraction(cuda, name, mlp, npoint, nsample, n, c):
+    mod, osd = filled(PointnetSAModulePWCLONet(mlp=list(mlp), npoint=npoint, nsample=nsample), name)
+    xyz = cloud(1, 3, n)
+    feat = torch.randn(3, c, n, generator=torch.Generator().manual_seed(2)) if c else None
+    ref_xyz, ref_feat = M.set_abstraction(osd, name, npoint, nsample, xyz, feat)
+    idx = O.knn_point_with_dist(nsample, xyz, ref_xyz)[1]
+    fsa = fused.FusedSA(mod.to(cuda))
+    out = fsa(xyz.to(cuda), ref_xyz.to(cuda),
+              feat.permute(0, 2, 1).contiguous().to(cuda) if c else None, idx.to(cuda))
+    close(out.permute(0, 2, 1), ref_feat)
+
+
+# ------------------------------------------------------------------------------------------------------
+import json
+import os
+
+import torch.nn.functional as F
+
+from pwclonet_pylidarslam_amd import synthetic
+from pwclonet_pylidarslam_amd.pointnet2_ops.pointnet2_modules import PointnetFPModulePWCLONet
+from pwclonet_pylidarslam_amd.pwclonet import CostVolume, FlowPredictor, PoseCalculator, PWCLONet
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+pm = lambda t: t.permute(0, 2, 1).contiguous()      # (B,C,N) <-> (B,N,C)
+
+
+@pytest.mark.parametrize("c2,n2,n1", [(32, 512, 128), (16, 333, 90), (64, 256, 64)])
+def test_fused_set_upconv(cuda, c2, n2, n1):
+    name = "pose_warp_refinement_2.setupconv_features"
+    mod, osd = filled(PointnetFPModulePWCLONet(nsample=8, mlp=[64, 128, 64], post_mlp=[64 + c2, 64],
+                                               radius=0.2, knn=True, use_xyz=True, bn=True), name)
+    xyz2, xyz1 = cloud(3, 2, n2), cloud(4, 2, n1)
+    g = torch.Generator().manual_seed(5)
+    f2, f1 = torch.randn(2, c2, n2, generator=g), torch.randn(2, 64, n1, generator=g)
+    ref = M.set_upconv(osd, name, 8, xyz2, xyz1, f2, f1)
+    idx = O.knn_point_with_dist(8, xyz1, xyz2)[1]
+    up = fused.FusedUpconv(mod.to(cuda))
+    out = up(xyz2.to(cuda), xyz1.to(cuda), pm(f2).to(cuda), pm(f1).to(cuda), idx.to(cuda))
+    close(pm(out), ref)
+
+
+@pytest.mark.parametrize("nq,ns,c,s,n", [(32, 4, 64, 256, 256), (6, 4, 64, 256, 256), (6, 4, 32, 512, 512),
+                                          (6, 4, 16, 301, 280), (32, 4, 64, 70, 90)])
+def test_fused_cost_volume(cuda, nq, ns, c, s, n):
+    name = "cost_volume"
+    mod, osd = filled(CostVolume(nsample=ns, nsample_q=nq, in_channel1=c, in_channel2=c,
+                                 mlp1=[128, 64, 64], mlp2=[128, 64]), name)
+    g = torch.Generator().manual_seed(6)
+    x1, x2 = pm(cloud(7, 2, s)), pm(cloud(8, 2, n))          # (B,3,S) as the oracle wants
+    p1, p2 = torch.randn(2, c, s, generator=g), torch.randn(2, c, n, generator=g)
+    taps = {}
+    ref = M.cost_volume(osd, name, ns, nq, x1, p1, x2, p2, taps, "cv")
+    cv = fused.FusedCostVolume(mod.to(cuda))
+    out = cv(pm(x1).to(cuda), pm(p1).to(cuda), pm(x2).to(cuda), pm(p2).to(cuda),
+             idx_q=taps["cv.idx_q"].to(cuda), idx=taps["cv.idx"].to(cuda))
+    close(pm(out), ref, rel=2e-5)
+
+
+def test_fused_pointwise_and_pose_head(cuda):
+    g = torch.Generator().manual_seed(9)
+    for chans in ((64, 64, 64), (32, 64, 64), (16, 64, 64), (64, 64, 32), (128, 64)):
+        fp, osd = filled(FlowPredictor(in_channel=sum(chans), mlp=[128, 64]), "l4_flow_predictor")
+        srcs = [torch.randn(2, c, 203, generator=g) for c in chans]
+        ref = M.flow_predictor(osd, "l4_flow_predictor", srcs[0], srcs[1], srcs[2] if len(srcs) > 2 else None)
+        out = fused.FusedPointwise(fp.to(cuda).mlp_convs, list(chans))(*[pm(s).to(cuda) for s in srcs])
+        close(pm(out), ref)
+    pc, osd = filled(PoseCalculator(in_channel=64, out_channel=256, kernel_size=1, padding="valid",
+                                    activation=None, squeeze=False), "pose_calculator_4")
+    emb, mask = torch.randn(3, 64, 1000, generator=g), torch.randn(3, 64, 1000, generator=g) * 3
+    rq, rt = M.pose_calculator(osd, "pose_calculator_4", emb, F.softmax(mask, dim=2))
+    q, t = fused.FusedPoseHead(pc.to(cuda))(pm(emb).to(cuda), pm(mask).to(cuda))
+    close(q, rq.squeeze(2))
+    close(t, rt.squeeze(2))
+
+
+def test_fps_with_xyz_and_point_major_warp(cuda):
+    x = cloud(21, 3, 3000)
+    idx, new_xyz = fused.fps_with_xyz(x.to(cuda), 700)
+    ref = O.furthest_point_sampling(x, 700)
+    assert torch.equal(idx.cpu(), ref)
+    assert torch.equal(new_xyz.cpu(), torch.gather(x, 1, ref.long().unsqueeze(-1).expand(-1, -1, 3)))
+    g = torch.Generator().manual_seed(3)
+    q = F.normalize(torch.randn(3, 4, generator=g), dim=1)
+    t = torch.randn(3, 3, generator=g)
+    ref_w = M.warp(pm(x), q.reshape(3, 4, 1), t.reshape(3, 3, 1))
+    out = fused.quat_warp_pm(x.to(cuda), q.to(cuda), t.to(cuda))
+    torch.testing.assert_close(pm(out.cpu()), ref_w, rtol=1e-5, atol=1e-5)
+
+
+def _net(dev):
+    net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(dev), scalar_last=False,
+                        log_mode="none"))
+    params.fill_state_dict(net.state_dict())
+    return net.to(dev).eval()
+
+
+@pytest.mark.parametrize("case", ["n1024_b2", "n8192_b1"])
+def test_fused_network_against_reference_golden(cuda, case):
+    z = np.load(os.path.join(GOLDEN, "pwclonet_%s.npz" % case))
+    meta = json.loads(str(z["meta"]))
+    if meta["generator"] == "uniform":
+        pc1, pc2 = synthetic.uniform_pair(meta["seed"], meta["npoints"], meta["batch"])
+    else:
+        pc1, pc2, _, _ = synthetic.kitti_like_pair(meta["seed"], meta["npoints"], meta["batch"])
+    x1 = torch.from_numpy(pc1[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    x2 = torch.from_numpy(pc2[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    net = _net(cuda)
+    fnet = fused.FusedPWCLONet(net)
+    pose, inter = fnet(x1, x2, return_intermediates=True)
+    ref = torch.from_numpy(z["pose_params"])
+    err = (pose.cpu() - ref).abs().max().item()
+    assert err < 1e-4, err
+    # level-1 sampled coordinates are exact, level-3 features match the reference's tap
+    assert torch.equal(inter["x11"].cpu(), torch.from_numpy(z["f1.psa_1.new_xyz"]))
+    close(pm(inter["f13"]), torch.from_numpy(z["f1.psa_3.new_features"]), rel=2e-5)
+    close(pm(inter["flow"]), torch.from_numpy(z["cv3.out"]), rel=5e-5)
+    # and the unfused module path agrees with the fused one
+    with torch.no_grad():
+        eager, _ = net(x1, None, x2, None)
+    torch.testing.assert_close(pose, eager, rtol=0, atol=5e-5)
