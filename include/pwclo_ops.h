@@ -179,6 +179,17 @@ void cv_fused_b_kernel_wrapper(int b, int s, int k, int c, const float *xyz1, co
  * (PW/pose_calculator.py:58). */
 void masked_pool_kernel_wrapper(int b, int n, const float *emb, const float *mask, float *out);
 
+/* Whole pose head of one pyramid level in one launch: the masked pooling above, PoseCalculator's
+ * three 1x1 convolutions (w_qt (256,64), w_q (4,256), w_t (3,256) + biases; eval mode, dropout =
+ * identity; PW/pose_calculator.py:47-86), and -- when q_prev (b,4) / t_prev (b,3) are given --
+ * the pose composition of PoseWarpRefinement (PW/pose_warp_refinement.py:139,148).  Writes q_out
+ * (b,4), t_out (b,3) and this level's row [t, q/|q|] at pose_row + i*row_stride (pwclo_net.py:195-205). */
+void pose_head_fused_kernel_wrapper(int b, int n, const float *emb, const float *mask,
+                                    const float *w_qt, const float *b_qt, const float *w_q,
+                                    const float *b_q, const float *w_t, const float *b_t,
+                                    const float *q_prev, const float *t_prev, float *q_out,
+                                    float *t_out, float *pose_row, int row_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,7 @@ SIGNATURES = {
     "cv_fused_a2_kernel_wrapper": ([_i] * 4 + [_F] * 6, None),
     "cv_fused_b_kernel_wrapper": ([_i] * 4 + [_F] * 6, None),
     "masked_pool_kernel_wrapper": ([_i, _i, _F, _F, _F], None),
+    "pose_head_fused_kernel_wrapper": ([_i, _i] + [_F] * 13 + [_i], None),
 }
 
 _lib = None

@@ -391,6 +391,109 @@ __global__ __launch_bounds__(64 * MP_PARTS) void masked_pool_kernel(int n, const
   }
 }
 
+// ---- fused pose head ------------------------------------------------------------------------------------
+// One workgroup per cloud does everything between the last per-point tensor and the pose:
+//   pooled = sum_n emb * softmax_n(mask)                                  (pose_calculator.py:58)
+//   big = W_qt pooled + b_qt (64 -> 256); q_det = normalise(W_q big + b_q); t_det = W_t big + b_t
+//   level 4 (q_prev == nullptr): q = q_det, t = t_det                      (pwclo_net.py:174)
+//   refinement levels: q = q_det (x) q_coarse, t = q_det (x) (0,t_coarse) (x) q_det^-1 + t_det
+//                                                                          (pose_warp_refinement.py:139,148)
+//   pose_row = [t, q / (sqrt(|q|^2 + 1e-10) + 1e-10)]                       (pwclo_net.py:195-205)
+// Replaces ~25 tiny torch launches per level.  Dropout is the identity in eval mode.
+struct PoseHeadArgs {
+  const float *emb, *mask;          // (B,N,64) point-major
+  const float *w_qt, *b_qt;         // (256,64), (256)
+  const float *w_q, *b_q;           // (4,256), (4)
+  const float *w_t, *b_t;           // (3,256), (3)
+  const float *q_prev, *t_prev;     // (B,4), (B,3) or nullptr
+  float *q_out, *t_out;             // (B,4), (B,3)
+  float *pose_row;                  // (B, row_stride) base of this level's row; 7 floats written
+  int n, row_stride;
+};
+
+__device__ __forceinline__ void quat_mul(const float *a, const float *b, float *r) {
+  r[0] = ((a[0] * b[0] - a[1] * b[1]) - a[2] * b[2]) - a[3] * b[3];
+  r[1] = ((a[0] * b[1] + a[1] * b[0]) + a[2] * b[3]) - a[3] * b[2];
+  r[2] = ((a[0] * b[2] - a[1] * b[3]) + a[2] * b[0]) + a[3] * b[1];
+  r[3] = ((a[0] * b[3] + a[1] * b[2]) - a[2] * b[1]) + a[3] * b[0];
+}
+
+__global__ __launch_bounds__(64 * MP_PARTS) void pose_head_kernel(PoseHeadArgs a) {
+  __shared__ float red[MP_PARTS][64];
+  __shared__ float red2[MP_PARTS][64];
+  __shared__ float pooled[64];
+  __shared__ float big[256];
+  __shared__ float qt[8];
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6, b = blockIdx.x, n = a.n;
+  const float *e = a.emb + (size_t)b * n * 64, *m = a.mask + (size_t)b * n * 64;
+  float mx = -INFINITY;
+  for (int i = part; i < n; i += MP_PARTS) mx = fmaxf(mx, m[(size_t)i * 64 + c]);
+  red[part][c] = mx;
+  __syncthreads();
+  mx = red[0][c];
+#pragma unroll
+  for (int q = 1; q < MP_PARTS; ++q) mx = fmaxf(mx, red[q][c]);
+  __syncthreads();
+  float den = 0.f, num = 0.f;
+  for (int i = part; i < n; i += MP_PARTS) {
+    const float ex = expf(m[(size_t)i * 64 + c] - mx);
+    den += ex;
+    num += ex * e[(size_t)i * 64 + c];
+  }
+  red[part][c] = den;
+  red2[part][c] = num;
+  __syncthreads();
+  if (part == 0) {
+    float d = 0.f, s = 0.f;
+#pragma unroll
+    for (int q = 0; q < MP_PARTS; ++q) { d += red[q][c]; s += red2[q][c]; }
+    pooled[c] = s / d;
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {                       // conv1d_q_t: 64 -> 256
+    const float *w = a.w_qt + threadIdx.x * 64;
+    float acc = a.b_qt[threadIdx.x];
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) acc += w[k] * pooled[k];
+    big[threadIdx.x] = acc;
+  }
+  __syncthreads();
+  if (part < 7) {                                // conv1d_q (4 rows) and conv1d_t (3 rows): 256 -> 1 each
+    const float *w = part < 4 ? a.w_q + part * 256 : a.w_t + (part - 4) * 256;
+    float acc = 0.f;
+    for (int k = c; k < 256; k += 64) acc += w[k] * big[k];
+    acc = wave_allreduce_f32(acc, [](float x, float y) { return x + y; });
+    if (c == 0) qt[part] = acc + (part < 4 ? a.b_q[part] : a.b_t[part - 4]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float qd[4] = {qt[0], qt[1], qt[2], qt[3]}, td[3] = {qt[4], qt[5], qt[6]};
+    const float nq = sqrtf((((qd[0] * qd[0] + qd[1] * qd[1]) + qd[2] * qd[2]) + qd[3] * qd[3]) + 1e-10f) + 1e-10f;
+    for (int i = 0; i < 4; ++i) qd[i] = qd[i] / nq;
+    float q[4], t[3];
+    if (a.q_prev) {
+      const float *qc = a.q_prev + b * 4, *tc = a.t_prev + b * 3;
+      quat_mul(qd, qc, q);
+      const float q2 = (((qd[0] * qd[0] + qd[1] * qd[1]) + qd[2] * qd[2]) + qd[3] * qd[3]) + 1e-10f;
+      const float qi[4] = {qd[0] / q2, (qd[1] * -1.0f) / q2, (qd[2] * -1.0f) / q2, (qd[3] * -1.0f) / q2};
+      const float p[4] = {0.f, tc[0], tc[1], tc[2]};
+      float r1[4], r2[4];
+      quat_mul(qd, p, r1);
+      quat_mul(r1, qi, r2);
+      t[0] = r2[1] + td[0]; t[1] = r2[2] + td[1]; t[2] = r2[3] + td[2];
+    } else {
+      for (int i = 0; i < 4; ++i) q[i] = qd[i];
+      for (int i = 0; i < 3; ++i) t[i] = td[i];
+    }
+    for (int i = 0; i < 4; ++i) a.q_out[b * 4 + i] = q[i];
+    for (int i = 0; i < 3; ++i) a.t_out[b * 3 + i] = t[i];
+    const float nn = sqrtf((((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]) + 1e-10f) + 1e-10f;
+    float *row = a.pose_row + (size_t)b * a.row_stride;
+    row[0] = t[0]; row[1] = t[1]; row[2] = t[2];
+    for (int i = 0; i < 4; ++i) row[3 + i] = q[i] / nn;
+  }
+}
+
 // ---- launch helpers ------------------------------------------------------------------------------------
 template <typename Kern, typename Args>
 static void launch_persistent(Kern kern, bool &attr_set, int lds_bytes, long long ntiles, const Args &a) {
@@ -511,4 +614,15 @@ extern "C" void masked_pool_kernel_wrapper(int b, int n, const float *emb, const
   if (b <= 0 || n <= 0) return;
   hipLaunchKernelGGL(masked_pool_kernel, dim3(b), dim3(64 * MP_PARTS), 0, current_stream(), n, emb, mask, out);
   check_launch("masked_pool");
+}
+
+extern "C" void pose_head_fused_kernel_wrapper(int b, int n, const float *emb, const float *mask,
+                                               const float *w_qt, const float *b_qt, const float *w_q,
+                                               const float *b_q, const float *w_t, const float *b_t,
+                                               const float *q_prev, const float *t_prev, float *q_out,
+                                               float *t_out, float *pose_row, int row_stride) {
+  if (b <= 0 || n <= 0) return;
+  PoseHeadArgs a{emb, mask, w_qt, b_qt, w_q, b_q, w_t, b_t, q_prev, t_prev, q_out, t_out, pose_row, n, row_stride};
+  hipLaunchKernelGGL(pose_head_kernel, dim3(b), dim3(64 * MP_PARTS), 0, current_stream(), a);
+  check_launch("pose_head_fused");
 }

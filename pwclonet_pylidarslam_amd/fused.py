@@ -245,21 +245,25 @@ def masked_pool(emb, mask):
 
 
 class FusedPoseHead:
-    """``PoseCalculator`` after the pooling: 64 -> 256 -> (q 4, t 3), eval mode (no dropout)."""
+    """``PoseCalculator`` (+ the pose composition of the refinement levels) in one launch."""
 
     def __init__(self, module):
-        g = lambda blk: (blk.conv.weight.detach().squeeze(-1), blk.conv.bias.detach())
+        g = lambda blk: (blk.conv.weight.detach().squeeze(-1).contiguous(), blk.conv.bias.detach().contiguous())
         self.w_qt, self.b_qt = g(module.conv1d_q_t)
         self.w_q, self.b_q = g(module.conv1d_q)
         self.w_t, self.b_t = g(module.conv1d_t)
 
-    def __call__(self, emb, mask):
-        pooled = masked_pool(emb, mask)                                   # (B,64)
-        big = torch.nn.functional.linear(pooled, self.w_qt, self.b_qt)    # (B,256)
-        q = torch.nn.functional.linear(big, self.w_q, self.b_q)
-        q = q / (torch.sqrt(torch.sum(q * q, dim=1, keepdim=True) + 1e-10) + 1e-10)
-        t = torch.nn.functional.linear(big, self.w_t, self.b_t)
-        return q, t                                                       # (B,4), (B,3)
+    def __call__(self, emb, mask, pose_params, level_row, q_prev=None, t_prev=None):
+        """emb, mask (B,N,64); pose_params (B,4,7) output buffer, `level_row` = which row to fill;
+        q_prev (B,4) / t_prev (B,3) = coarse pose to refine (None at level 4).  -> q (B,4), t (B,3)."""
+        B, N, _ = emb.shape
+        q = torch.empty((B, 4), dtype=torch.float32, device=emb.device)
+        t = torch.empty((B, 3), dtype=torch.float32, device=emb.device)
+        row = pose_params.data_ptr() + 4 * 7 * level_row
+        _lib.call("pose_head_fused_kernel_wrapper", emb.device, B, N, _p(emb), _p(mask), _p(self.w_qt),
+                  _p(self.b_qt), _p(self.w_q), _p(self.b_q), _p(self.w_t), _p(self.b_t), _p(q_prev),
+                  _p(t_prev), _p(q), _p(t), row, 28)
+        return q, t
 
 
 # ---- whole network --------------------------------------------------------------------------------------
@@ -296,9 +300,7 @@ class FusedPWCLONet:
                      head=FusedPoseHead(m.pose_calculator), last=m.last_pose_estimation)
             self.pwr.append(d)
 
-    def _refine(self, d, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev):
-        pw = self.pw
-        B = x1.shape[0]
+    def _refine(self, d, row, pose, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev):
         idx_up = knn(8, x1_prev, x1)
         up_feat = d["up_f"](x1, x1_prev, f1, emb_prev, idx_up)
         up_mask = d["up_m"](x1, x1_prev, f1, mask_prev, idx_up)
@@ -306,10 +308,7 @@ class FusedPWCLONet:
         resid = d["cv"](warped, f1, x2, f2)
         emb = d["pred_f"](f1, resid, up_feat)
         mask = up_mask if d["last"] else d["pred_m"](up_mask, emb, f1)
-        q_det, t_det = d["head"](emb, mask)
-        q_c, t_c = q_prev.reshape(B, 4, 1), t_prev.reshape(B, 3, 1)
-        q = pw.mul_point_q(q_det.reshape(B, 4, 1), q_c).squeeze(2)              # pose_warp_refinement.py:139
-        t = pw.warp(t_c, q_det.reshape(B, 4, 1), t_det.reshape(B, 3, 1)).squeeze(2)   # :148
+        q, t = d["head"](emb, mask, pose, row, q_prev, t_prev)
         return q, t, emb, mask
 
     @torch.no_grad()
@@ -332,16 +331,12 @@ class FusedPWCLONet:
         # flow_feature_encoding samples the same cloud as psa_4(frame 1): reuse x14
         emb4 = self.ffe(x13, x14, flow, knn(self.ffe_cfg[1], x13, x14))
         mask4 = self.l4_pred(f14, emb4)
-        q4, t4 = self.l4_head(emb4, mask4)
+        pose = torch.empty((B, 4, 7), dtype=torch.float32, device=x.device)   # rows = levels 1..4
+        q4, t4 = self.l4_head(emb4, mask4, pose, 3)
 
-        q3, t3, emb3, mask3 = self._refine(self.pwr[0], x13, f13, x23, f23, x14, emb4, mask4, q4, t4)
-        q2, t2, emb2, mask2 = self._refine(self.pwr[1], x12, f12, x22, f22, x13, emb3, mask3, q3, t3)
-        q1, t1, emb1, mask1 = self._refine(self.pwr[2], x11, f11, x21, f21, x12, emb2, mask2, q2, t2)
-
-        unit = lambda q: q / (torch.sqrt(torch.sum(q * q, dim=-1, keepdim=True) + 1e-10) + 1e-10)
-        rows = [torch.cat((t, unit(q)), dim=-1).reshape(-1, 1, 7)
-                for q, t in ((q1, t1), (q2, t2), (q3, t3), (q4, t4))]
-        pose = torch.cat(rows, dim=1)
+        q3, t3, emb3, mask3 = self._refine(self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4)
+        q2, t2, emb2, mask2 = self._refine(self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3)
+        q1, t1, emb1, mask1 = self._refine(self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2)
         if return_intermediates:
             return pose, dict(x11=x11, f11=f11, f13=f13, flow=flow, emb4=emb4, mask4=mask4, emb3=emb3,
                               mask3=mask3, emb1=emb1, mask1=mask1, q=(q1, q2, q3, q4), t=(t1, t2, t3, t4))

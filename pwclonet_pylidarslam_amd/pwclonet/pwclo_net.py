@@ -29,6 +29,31 @@ def _cfg(config, key, default=None):
     return getattr(config, key, default)
 
 
+class LazyLogDict(dict):
+    """``log_dict`` whose values are computed on first access.  The reference builds
+    ``embedding_mask`` / ``point_cloud`` inside forward (pwclo_net.py:186-193, with a D2H sync);
+    here the forward only keeps references and the softmax / norm / copies run when (and if)
+    a logger reads them."""
+
+    def __init__(self, mask_pm, cloud_pm, to_host):
+        super().__init__()
+        self._src = (mask_pm, cloud_pm, to_host)
+        dict.__setitem__(self, "embedding_mask", None)
+        dict.__setitem__(self, "point_cloud", None)
+
+    def __getitem__(self, key):
+        if dict.__getitem__(self, key) is None:
+            m1, pc, to_host = self._src
+            if to_host:
+                m1, pc = m1.cpu(), pc.cpu()
+            if key == "embedding_mask":
+                val = torch.linalg.norm(F.softmax(m1, dim=1), dim=-1, ord=2)
+            else:
+                val = pc
+            dict.__setitem__(self, key, val)
+        return dict.__getitem__(self, key)
+
+
 def _unit(q):
     return q / (torch.sqrt(torch.sum(q * q, dim=-1, keepdim=True) + 1e-10) + 1e-10)
 
@@ -104,12 +129,8 @@ class PWCLONet(nn.Module):
         if self._fused is not None and not self.training and points_f1 is None and points_f2 is None:
             pose, inter = self._fused(xyz_f1, xyz_f2, return_intermediates=True)
             log_dict = {}
-            if self.log_mode != "none":
-                m1, pc = inter["mask1"], inter["x11"]          # (B,N,64) / (B,N,3) point-major
-                if self.log_mode == "host":
-                    m1, pc = m1.cpu(), pc.cpu()
-                log_dict = {"embedding_mask": torch.linalg.norm(F.softmax(m1, dim=1), dim=-1, ord=2),
-                            "point_cloud": pc}
+            if self.log_mode != "none":                        # (B,N,64) / (B,N,3) point-major
+                log_dict = LazyLogDict(inter["mask1"], inter["x11"], self.log_mode == "host")
             return pose, log_dict
         cf = lambda z: z.permute(0, 2, 1).contiguous()
         B = xyz_f1.size(0)

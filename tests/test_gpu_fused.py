@@ -113,9 +113,23 @@ def test_fused_pointwise_and_pose_head(cuda):
                                     activation=None, squeeze=False), "pose_calculator_4")
     emb, mask = torch.randn(3, 64, 1000, generator=g), torch.randn(3, 64, 1000, generator=g) * 3
     rq, rt = M.pose_calculator(osd, "pose_calculator_4", emb, F.softmax(mask, dim=2))
-    q, t = fused.FusedPoseHead(pc.to(cuda))(pm(emb).to(cuda), pm(mask).to(cuda))
+    head = fused.FusedPoseHead(pc.to(cuda))
+    pose = torch.zeros(3, 4, 7, device=cuda)
+    q, t = head(pm(emb).to(cuda), pm(mask).to(cuda), pose, 3)
     close(q, rq.squeeze(2))
     close(t, rt.squeeze(2))
+    close(pose[:, 3, :3], rt.squeeze(2))
+    close(pose[:, 3, 3:], rq.squeeze(2))          # already unit: the row normalisation is a no-op
+    assert (pose[:, :3] == 0).all()
+    # refinement level: composition with a coarse pose (pose_warp_refinement.py:139,148)
+    qc = F.normalize(torch.randn(3, 4, generator=g), dim=1)
+    tc = torch.randn(3, 3, generator=g)
+    q2, t2 = head(pm(emb).to(cuda), pm(mask).to(cuda), pose, 1, qc.to(cuda), tc.to(cuda))
+    ref_q = M._hamilton(rq, qc.reshape(3, 4, 1)).squeeze(2)
+    ref_t = M.warp(tc.reshape(3, 3, 1), rq, rt).squeeze(2)
+    close(q2, ref_q)
+    close(t2, ref_t)
+    close(pose[:, 1, :3], ref_t)
 
 
 def test_fps_with_xyz_and_point_major_warp(cuda):
