@@ -110,6 +110,9 @@ def main():
                     help="host = the reference's in-forward D2H log_dict (default)")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph = replay one captured hipGraph per step (default); eager = Python launches")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight (graph launch only): 2 = one batch's FPS chain overlaps the "
+                         "other's neighbour-search/MLP kernels; 1 = strictly serial steps")
     ap.add_argument("--unfused", action="store_true",
                     help="reference-shaped module graph on the HIP ops (torch conv/BN) instead of the fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,7 +138,14 @@ def main():
         net.prepare_fused()
     x1, x2 = make_batch(args.batch, args.npoints, 1000 + rank, dev)
 
-    if args.launch == "graph":
+    pipe = None
+    if args.launch == "graph" and args.inflight > 1:
+        from pwclonet_pylidarslam_amd.graphed import PipelinedForward
+        pipe = PipelinedForward(net, depth=args.inflight)
+
+        def step():
+            return pipe(x1, x2)[0]
+    elif args.launch == "graph":
         from pwclonet_pylidarslam_amd.graphed import GraphedForward
         graphed = GraphedForward(net)
 
@@ -185,7 +195,8 @@ def main():
                        "global_batch": world * args.batch, "npoints": args.npoints,
                        "parallelism": "replicas x%d (no forward collective)" % world,
                        "log_dict": args.log_mode if args.launch == "eager" else "device (graph replay)",
-                       "launch": args.launch, "kernels": "module graph + torch conv/BN" if args.unfused
+                       "launch": args.launch, "batches_in_flight": args.inflight if pipe else 1,
+                       "kernels": "module graph + torch conv/BN" if args.unfused
                        else "fused gather+MFMA-MLP kernels (BN folded)"},
             "roofline": {"kernel": "group_points_kernel", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -51,3 +51,41 @@ class GraphedForward:
         graph.replay()
         self.last_log_dict = log
         return pose
+
+
+class PipelinedForward:
+    """Keeps `depth` forwards in flight: one captured graph + stream per slot, used round-robin.
+
+    Within one forward the furthest-point-sampling chain is a long dependent sequence that
+    occupies one CU per cloud (64 of 256 CUs at batch 32) while the rest of the chip waits; with
+    two batches in flight one batch's FPS runs under the other's neighbour-search / MLP kernels.
+    Throughput tool: each call returns the (static) output tensor of the slot it used, valid once
+    that slot's stream has been synchronised (``wait(slot)`` / ``wait_all()``)."""
+
+    def __init__(self, net, depth=2):
+        self.slots = [GraphedForward(net) for _ in range(depth)]
+        self.streams = None
+        self.events = [None] * depth
+        self._next = 0
+
+    def __call__(self, xyz_f1, xyz_f2):
+        if self.streams is None:
+            self.streams = [torch.cuda.Stream(device=xyz_f1.device) for _ in self.slots]
+        i = self._next
+        self._next = (i + 1) % len(self.slots)
+        st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream(xyz_f1.device))   # inputs produced on the caller's stream
+        with torch.cuda.stream(st):
+            out = self.slots[i](xyz_f1, xyz_f2)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self.events[i] = ev
+        return out, i
+
+    def wait(self, slot):
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()
+
+    def wait_all(self):
+        for s in self.streams or []:
+            s.synchronize()
