@@ -1,14 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: PWCLO-Net forward frame-pairs/s on 2x8192-point KITTI-shaped pairs,
-batch 32 per GPU, fp32, eval mode (BASELINE.json metric / configs[2]).
+batch 32 per GPU, fp32, eval mode (BASELINE.json metric, configs[2]).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One process per GPU.  A step = one forward over one batch of 32 synthetic frame pairs already
-resident in HBM.  The path has no cross-rank exchange in forward (independent frame pairs), so
-ranks are pure replicas ("weak" scaling); the only collective is the max-over-ranks of the timed
-region.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+resident in HBM.  The forward has no cross-rank exchange (independent frame pairs), so the ranks
+are replicas ("weak" scaling); the only collectives are the barrier around the timed region and
+the MAX-reduce of its duration.  Rank 0 prints ONE JSON line.
+
+Timed region: W warm-up steps, then exactly K steps between two fences (device sync + barrier +
+device sync).  By default a step is one hipGraph replay and two batches are kept in flight
+(`--inflight 2`; DESIGN.md "Launch structure").
+
+`roofline`: after the timed region the same step runs once more eagerly with HIP events around
+every launch of the library (events recorded on the launch stream); the object reports the
+dominant kernel family by time -- the register-resident MFMA MLP stack (csrc/mlp_core.hpp, all
+fused_* kernels) -- as algorithmic FLOP / measured time against the fp32 MFMA peak, and `kernels`
+lists the other families with the bound that applies to them.  `cpu_baseline`: the CPU oracle
+(bit-identical to the imported reference) on a few B=1 pairs on this box's host cores.
 """
 import argparse
 import json
@@ -22,10 +33,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pwclonet_pylidarslam_amd import _lib, synthetic  # noqa: E402
+from pwclonet_pylidarslam_amd import _lib, dist_util, synthetic  # noqa: E402
 from pwclonet_pylidarslam_amd.pwclonet import PWCLONet  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
@@ -45,47 +57,85 @@ def make_batch(batch, npoints, seed, device):
     return out[0], out[1]
 
 
-class KernelTimer:
-    """HIP-event timing of one launcher of the C ABI, on the stream it is launched on (torch's
-    current stream -- _lib.call forwards that stream to the library)."""
+class LaunchProfiler:
+    """Collects (launcher name, annotated work, start/end HIP events) for every C-ABI launch."""
 
-    def __init__(self, name, bytes_fn):
-        self.name, self.bytes_fn = name, bytes_fn
-        self.events, self.bytes = [], 0.0
-        self._orig = None
+    def __init__(self):
+        self.rows = []
 
-    def __enter__(self):
-        self._orig = _lib.call
-        orig, me = self._orig, self
+    def add(self, name, meta, start, end):
+        self.rows.append((name, meta or {}, start, end))
 
-        def call(name, device, *args):
-            if name != me.name:
-                return orig(name, device, *args)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            orig(name, device, *args)
-            e.record()
-            me.events.append((s, e))
-            me.bytes += me.bytes_fn(*args)
-
-        _lib.call = call
-        return self
-
-    def __exit__(self, *exc):
-        _lib.call = self._orig
-
-    def result(self):
-        ms = sum(s.elapsed_time(e) for s, e in self.events)
-        return len(self.events), ms, self.bytes
+    def summary(self):
+        fam = {}
+        for name, meta, s, e in self.rows:
+            f = meta.get("family", "other")
+            d = fam.setdefault(f, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "units": 0.0,
+                                   "iters": 0, "by_name": {}})
+            ms = s.elapsed_time(e)
+            d["ms"] += ms
+            d["launches"] += 1
+            for k in ("flops", "bytes", "units", "iters"):
+                d[k] += meta.get(k, 0)
+            bn = d["by_name"].setdefault(name, [0.0, 0])
+            bn[0] += ms
+            bn[1] += 1
+        return fam
 
 
-def group_points_bytes(b, c, n, s, k, *ptrs):
-    return 4.0 * b * (s * k + c * n + c * s * k)  # SURVEY.md section 8d: idx + source + out
+def instrumented_pass(net, x1, x2):
+    """One eager forward of the same step with per-launch HIP events (graphs cannot be timed
+    kernel by kernel from inside the process)."""
+    prof = LaunchProfiler()
+    with torch.no_grad():
+        net(x1, None, x2, None)           # warm (allocator, one-time attributes)
+        torch.cuda.synchronize()
+        _lib.profiler = prof
+        try:
+            net(x1, None, x2, None)
+        finally:
+            _lib.profiler = None
+    torch.cuda.synchronize()
+    return prof.summary()
+
+
+def roofline_objects(fam):
+    total_ms = sum(d["ms"] for d in fam.values()) or 1.0
+    mlp = fam.get("mlp", {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+    tf = mlp["flops"] / 1e12 / (mlp["ms"] / 1e3) if mlp["ms"] > 0 else 0.0
+    roof = {"kernel": "mlp_core MFMA stack (sa/upconv/pointwise/cv_a1/cv_a2/cv_b kernels)",
+            "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "launches": mlp["launches"],
+            "avg_launch_us": 1e3 * mlp["ms"] / max(mlp["launches"], 1),
+            "algorithmic_gflop_per_step": mlp["flops"] / 1e9,
+            "algorithmic_mb_per_step": mlp["bytes"] / 1e6,
+            "share_of_kernel_time": mlp["ms"] / total_ms,
+            "timing": "HIP events on the launch stream, one eager pass after the timed region"}
+    kernels = {}
+    if "fps" in fam:
+        d = fam["fps"]
+        kernels["furthest_point_sampling"] = {
+            "bound": "latency (dependent arg-max chain, one workgroup per cloud)", "ms": d["ms"],
+            "launches": d["launches"], "ns_per_iteration": 1e6 * d["ms"] / max(d["iters"], 1),
+            "gpoint_visits_per_s": d["units"] / 1e9 / (d["ms"] / 1e3) if d["ms"] else 0.0,
+            "hbm_gbs": d["bytes"] / 1e9 / (d["ms"] / 1e3) if d["ms"] else 0.0,
+            "share_of_kernel_time": d["ms"] / total_ms}
+    if "knn" in fam:
+        d = fam["knn"]
+        kernels["knn_point"] = {
+            "bound": "valu (distance + select), HBM traffic negligible", "ms": d["ms"], "launches": d["launches"],
+            "gdist_per_s": d["units"] / 1e9 / (d["ms"] / 1e3) if d["ms"] else 0.0,
+            "hbm_gbs": d["bytes"] / 1e9 / (d["ms"] / 1e3) if d["ms"] else 0.0,
+            "share_of_kernel_time": d["ms"] / total_ms}
+    if "other" in fam:
+        kernels["other"] = {"ms": fam["other"]["ms"], "launches": fam["other"]["launches"],
+                            "share_of_kernel_time": fam["other"]["ms"] / total_ms}
+    return roof, kernels
 
 
 def cpu_baseline(net, npoints, pairs):
-    """Oracle (CPU restatement of the reference path, bit-identical to the imported reference) on
-    `pairs` sequential B=1 2xN pairs.  Baseline only."""
+    """The CPU oracle (restatement of the reference path, bit-identical to the imported reference
+    in the build container) on `pairs` sequential B=1 2xN pairs.  A baseline, not a target."""
     from oracle import model as omodel
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     x1, x2 = make_batch(pairs, npoints, 999, torch.device("cpu"))
@@ -95,19 +145,20 @@ def cpu_baseline(net, npoints, pairs):
         omodel.pwclonet_forward(sd, x1[i:i + 1], x2[i:i + 1])
     dt = time.perf_counter() - t0
     return {"value": pairs / dt, "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d sequential B=1 2x%d-pt pairs, oracle.model (torch CPU convs on %d threads, "
-                      "C ext ops + knn single-threaded)" % (pairs, npoints, torch.get_num_threads())}
+            "sample": "%d sequential B=1 2x%d-pt pairs through oracle.model: torch CPU convolutions on %d "
+                      "threads, C extension ops and knn single-threaded (%.1f s)"
+                      % (pairs, npoints, torch.get_num_threads(), dt)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="frame pairs per GPU per step")
     ap.add_argument("--npoints", type=int, default=8192)
     ap.add_argument("--log-mode", default="host", choices=["host", "device", "none"],
-                    help="host = the reference's in-forward D2H log_dict (default)")
+                    help="host = the reference's log_dict on the host (lazy: built when read)")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph = replay one captured hipGraph per step (default); eager = Python launches")
     ap.add_argument("--inflight", type=int, default=2,
@@ -116,19 +167,15 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="reference-shaped module graph on the HIP ops (torch conv/BN) instead of the fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=4)
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=6)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = dist_util.env_world()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    dist_util.init("nccl", dev)
 
     _lib.load()
     torch.manual_seed(1234)
@@ -160,29 +207,15 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    timer = KernelTimer("group_points_kernel_wrapper", group_points_bytes)
-    fence()
+    dist_util.fence(dev)
     t0 = time.perf_counter()
-    with timer:
-        for _ in range(args.steps):
-            pose = step()
-    fence()
-    dt = time.perf_counter() - t0
+    for _ in range(args.steps):
+        pose = step()
+    dist_util.fence(dev)
+    dt = dist_util.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(pose).all()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     if rank == 0:
-        launches, ms, nbytes = timer.result()
-        achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
         out = {
             "metric": "PWCLO-Net forward frame-pairs/sec, 2x8192-pt KITTI pair, batch 32",
             "value": world * args.batch * args.steps / dt, "unit": "frame-pairs/s",
@@ -194,21 +227,19 @@ def main():
                                    % (args.npoints, args.batch),
                        "global_batch": world * args.batch, "npoints": args.npoints,
                        "parallelism": "replicas x%d (no forward collective)" % world,
-                       "log_dict": args.log_mode if args.launch == "eager" else "device (graph replay)",
                        "launch": args.launch, "batches_in_flight": args.inflight if pipe else 1,
                        "kernels": "module graph + torch conv/BN" if args.unfused
-                       else "fused gather+MFMA-MLP kernels (BN folded)"},
-            "roofline": {"kernel": "group_points_kernel", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "launches": launches,
-                         "avg_launch_us": 1e3 * ms / max(launches, 1),
-                         "algorithmic_bytes_per_step": nbytes / max(args.steps, 1)},
+                       else "fused gather+MFMA-MLP kernels (BN folded)",
+                       "log_dict": args.log_mode + " (lazy)"},
         }
+        if not args.no_roofline and not args.unfused:
+            roof, kernels = roofline_objects(instrumented_pass(net, x1, x2))
+            out["roofline"] = roof
+            out["kernels"] = kernels
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(net, args.npoints, args.cpu_pairs)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    dist_util.finish()
 
 
 if __name__ == "__main__":

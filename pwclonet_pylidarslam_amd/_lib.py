@@ -76,10 +76,32 @@ def check(what):
         raise RuntimeError("%s failed (error %d): %s" % (what, code, msg))
 
 
+# Optional launch profiler (bench.py / tools): an object with .add(name, meta, start_evt, end_evt).
+# Wrappers describe the next launch's algorithmic work with annotate(); both are no-ops otherwise.
+profiler = None
+_meta = None
+
+
+def annotate(**meta):
+    """Algorithmic work of the NEXT launch (flops / bytes / units), consumed by the profiler."""
+    global _meta
+    _meta = meta
+
+
 def call(name, device, *args):
     """Launch `name` on torch's current stream of `device` and check the sticky error."""
+    global _meta
     lib = load()
     with torch.cuda.device(device):
-        lib.pwclo_set_stream(ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
-        getattr(lib, name)(*args)
+        stream = torch.cuda.current_stream(device)
+        lib.pwclo_set_stream(ctypes.c_void_p(stream.cuda_stream))
+        if profiler is None:
+            getattr(lib, name)(*args)
+        else:   # HIP events on the very stream the kernel is launched on
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(stream)
+            getattr(lib, name)(*args)
+            e.record(stream)
+            profiler.add(name, _meta, s, e)
+    _meta = None
     check(name)

@@ -51,6 +51,16 @@ def chain_map(cout_prev, nb):
     return [c if c < cout_prev else -1 for c in range(16 * nb)]
 
 
+def layer_floats(nbi, nbo):
+    """Floats of one packed layer (csrc/mlp_core.hpp: layer_floats)."""
+    return nbo * nbi * 256 + nbo * 16
+
+
+def stack_macs(shared_mlp):
+    """Algorithmic multiply-accumulates per pixel of a SharedMLP (real, unpadded channel counts)."""
+    return sum(int(l.conv.weight.shape[0]) * int(l.conv.weight.shape[1]) for l in shared_mlp)
+
+
 def pack_stack(shared_mlp, first_map):
     """Pack every layer of a SharedMLP whose first layer reads the physical order `first_map`.
     Returns (packed float tensor, [padded widths])."""
@@ -92,6 +102,7 @@ class FusedSA:
         self.c_out = convs[-1].conv.weight.shape[0]
         assert self.c_out == self.widths[-1], "last layer width must be a multiple of 16"
         self.nsample = module.nsample
+        self.macs = stack_macs(module.mlp_module)
 
     def __call__(self, xyz, new_xyz, feat_pm, idx):
         """xyz (B,N,3), new_xyz (B,S,3), feat_pm (B,N,C) point-major or None, idx (B,S,K) int32
@@ -99,6 +110,8 @@ class FusedSA:
         B, N, _ = xyz.shape
         S, K = idx.shape[1], idx.shape[2]
         out = torch.empty((B, S, self.c_out), dtype=torch.float32, device=xyz.device)
+        _lib.annotate(family="mlp", flops=2.0 * B * S * K * self.macs,
+                      bytes=4.0 * B * (S * K + S * K * (3 + self.c_feat) + 3 * S + S * self.c_out))
         _lib.call("sa_fused_kernel_wrapper", xyz.device, B, N, S, K, self.c_feat, *self.widths,
                   _p(xyz), _p(new_xyz), _p(feat_pm), _p(idx), _p(self.packed), _p(out))
         return out
@@ -113,6 +126,8 @@ def fps_with_xyz(xyz, npoint):
     idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
     tmp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device) if N > 24576 else None
+    _lib.annotate(family="fps", units=float(B) * (npoint - 1) * N, iters=npoint - 1,
+                  bytes=4.0 * B * (3 * N + 4 * npoint))
     _lib.call("furthest_point_sampling_xyz_kernel_wrapper", xyz.device, B, N, npoint, _p(xyz), _p(tmp),
               _p(idx), _p(new_xyz))
     return idx, new_xyz
@@ -130,6 +145,9 @@ def quat_warp_pm(xyz, q, t):
 
 def knn(nsample, xyz, new_xyz):
     from .pointnet2_ops import _ext
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    _lib.annotate(family="knn", units=float(B) * S * N, bytes=4.0 * B * (3 * N + 3 * S + S * nsample))
     return _ext.knn_point(nsample, xyz, new_xyz)
 
 
@@ -147,11 +165,13 @@ class FusedPointwise:
         assert len(widths) in (1, 2)
         self.w1, self.w2 = widths[0], (widths[1] if len(widths) == 2 else 0)
         self.c_out = widths[-1]
+        self.macs, self.c_in = stack_macs(shared_mlp), cin
 
     def __call__(self, *sources):
         B, S, _ = sources[0].shape
         src = list(sources) + [None] * (3 - len(sources))
         out = torch.empty((B, S, self.c_out), dtype=torch.float32, device=sources[0].device)
+        _lib.annotate(family="mlp", flops=2.0 * B * S * self.macs, bytes=4.0 * B * S * (self.c_in + self.c_out))
         _lib.call("pointwise_fused_kernel_wrapper", out.device, B, S, *self.src_c, self.w1, self.w2,
                   _p(src[0]), _p(src[1]), _p(src[2]), _p(self.packed), _p(out))
         return out
@@ -173,11 +193,15 @@ class FusedUpconv:
         c2 = list(module.post_mlp)[0].conv.weight.shape[1] - 64
         self.post = FusedPointwise(module.post_mlp, [64, c2])
         self.nsample = module.nsample
+        self.macs = stack_macs(module.mlp)
 
     def pooled(self, xyz2, xyz1, feat1, idx):
         B, S, _ = xyz2.shape
         N = xyz1.shape[1]
         out = torch.empty((B, S, 64), dtype=torch.float32, device=xyz2.device)
+        K = idx.shape[2]
+        _lib.annotate(family="mlp", flops=2.0 * B * S * K * self.macs,
+                      bytes=4.0 * B * (S * K + S * K * 67 + 3 * S + 64 * S))
         _lib.call("upconv_fused_kernel_wrapper", xyz2.device, B, N, S, idx.shape[2], _p(xyz2), _p(xyz1),
                   _p(feat1), _p(idx), _p(self.packed), _p(out))
         return out
@@ -210,6 +234,9 @@ class FusedCostVolume:
         w3, wd3 = pack_stack(module.mlp3_convs, list(range(128 + c1)))  # [enc2 | feat1 | first], :176
         assert wd3 == [128, 64]
         self.w_b = torch.cat((wx2, w3)).contiguous()
+        self.macs_a1 = stack_macs(module.mlp_convs)
+        self.macs_a2 = stack_macs(module.mlp_conv_xyz_1) + stack_macs(module.mlp2_convs)
+        self.macs_b = stack_macs(module.mlp_conv_xyz_2) + stack_macs(module.mlp3_convs)
 
     def __call__(self, xyz1, feat1, xyz2, feat2, idx_q=None, idx=None):
         """xyz1 (B,S,3) (warped) frame-1 points, feat1 (B,S,C), xyz2 (B,N,3), feat2 (B,N,C),
@@ -222,14 +249,21 @@ class FusedCostVolume:
             idx_q = knn(kq, xyz2, xyz1)
         kp = 32 if kq > 16 else (16 if kq > 8 else 8)
         pix = torch.empty((B, S * kp, 64), dtype=torch.float32, device=dev)
+        c = self.c
+        _lib.annotate(family="mlp", flops=2.0 * B * S * kq * self.macs_a1,
+                      bytes=4.0 * B * (S * kq * (1 + 3 + c + 64) + S * (3 + c)))
         _lib.call("cv_fused_a1_kernel_wrapper", dev, B, N, S, kq, self.c, _p(xyz1), _p(feat1), _p(xyz2),
                   _p(feat2), _p(idx_q), _p(self.w_a1), _p(pix))
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
+        _lib.annotate(family="mlp", flops=2.0 * B * S * kq * self.macs_a2,
+                      bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
                   _p(self.w_a2), _p(pix), _p(first))
         if idx is None:
             idx = knn(k, xyz1, xyz1)
         out = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
+        _lib.annotate(family="mlp", flops=2.0 * B * S * k * self.macs_b,
+                      bytes=4.0 * B * (S * k * (1 + 3 + 64) + S * (3 + c + 64)))
         _lib.call("cv_fused_b_kernel_wrapper", dev, B, S, k, self.c, _p(xyz1), _p(feat1), _p(first),
                   _p(idx), _p(self.w_b), _p(out))
         return out

@@ -1,0 +1,192 @@
+"""CPU tests (``-m "not gpu"``) of the boundary and the host logic: the C-ABI library loads and
+exports every symbol declared in include/pwclo_ops.h, the Python bindings agree with the header,
+the module mirror keeps the reference's state_dict names, weight packing matches an explicit
+emulation of the MFMA operand layout, the product refuses CPU tensors (no fallback), and the
+2-rank (gloo) benchmark plumbing shards and reduces correctly.
+"""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "pwclo_ops.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.findall(r"\b(?:void|int|const char \*|void \*)\s*\*?\s*(\w+)\s*\(", text)
+
+
+def test_library_exports_every_declared_symbol():
+    from pwclonet_pylidarslam_amd import _lib, build
+    lib_path = build.build()                      # hipcc cross-compiles without a GPU
+    names = header_functions()
+    assert len(names) >= 25 and "group_points_kernel_wrapper" in names and "knn_point_kernel_wrapper" in names
+    lib = ctypes.CDLL(lib_path)
+    for n in names:
+        assert hasattr(lib, n), "libpwclo_hip.so does not export %s" % n
+    assert set(_lib.SIGNATURES) == set(names), set(_lib.SIGNATURES) ^ set(names)
+    loaded = _lib.load()
+    assert loaded.pwclo_abi_version() == 1
+    assert loaded.pwclo_last_error() == 0
+
+
+def test_reference_launcher_names_and_arity():
+    """The nine launchers keep the reference's names and parameter lists."""
+    from pwclonet_pylidarslam_amd import _lib
+    expected = {"gather_points_kernel_wrapper": 7, "gather_points_grad_kernel_wrapper": 7,
+                "furthest_point_sampling_kernel_wrapper": 6, "group_points_kernel_wrapper": 8,
+                "group_points_grad_kernel_wrapper": 8, "query_ball_point_kernel_wrapper": 8,
+                "three_nn_kernel_wrapper": 7, "three_interpolate_kernel_wrapper": 8,
+                "three_interpolate_grad_kernel_wrapper": 8}
+    for name, arity in expected.items():
+        assert len(_lib.SIGNATURES[name][0]) == arity, name
+
+
+def test_no_cpu_fallback_and_host_checks():
+    from pwclonet_pylidarslam_amd.pointnet2_ops import _ext, pointnet2_utils, pytorch_utils
+    x = torch.rand(1, 16, 3)
+    for fn in (lambda: _ext.furthest_point_sampling(x, 4),
+               lambda: _ext.knn_point(2, x, x),
+               lambda: pointnet2_utils.furthest_point_sample(x, 4),
+               lambda: pytorch_utils.knn_point(2, x, x),
+               lambda: _ext.group_points(x.transpose(1, 2).contiguous(), torch.zeros(1, 2, 2, dtype=torch.int32))):
+        with pytest.raises(RuntimeError, match="CPU not supported"):
+            fn()
+    with pytest.raises(RuntimeError, match="must be a float tensor"):
+        _ext.gather_points(x.double(), torch.zeros(1, 2, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="must be an int tensor"):
+        _ext.gather_points(x, torch.zeros(1, 2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="contiguous"):
+        _ext.gather_points(x.transpose(1, 2), torch.zeros(1, 2, dtype=torch.int32))
+
+
+def test_module_mirror_keeps_reference_state_dict():
+    from pwclonet_pylidarslam_amd.pwclonet import PWCLONet
+    net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device="cpu", scalar_last=False))
+    ref = json.load(open(os.path.join(GOLDEN, "state_shapes.json")))
+    sd = net.state_dict()
+    assert list(sd) == sorted(sd, key=list(sd).index) and set(sd) == set(ref)
+    assert all(list(sd[k].shape) == ref[k] for k in ref)
+    assert sum(p.numel() for p in net.parameters()) == 775068
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        net.eval()(torch.rand(1, 3, 128), None, torch.rand(1, 3, 128), None)
+    # a wrapper API detail the trainer relies on: forward returns (pose_params, log_dict)
+    assert net.nb_levels == 4 and net.log_mode == "host"
+
+
+def test_bn_folding_and_weight_packing_layout():
+    """pack_layer output == the operand each MFMA lane expects (csrc/mlp_core.hpp), checked by an
+    explicit emulation of v_mfma_f32_16x16x4_f32's A/B/D lane maps."""
+    from pwclonet_pylidarslam_amd import fused
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pytorch_utils as pt
+    torch.manual_seed(0)
+    mlp = pt.SharedMLP([19, 24, 32], bn=True).eval()
+    for layer in mlp:
+        layer.bn.bn.running_mean.uniform_(-1, 1)
+        layer.bn.bn.running_var.uniform_(0.5, 2)
+        layer.bn.bn.weight.data.uniform_(0.5, 1.5)
+        layer.bn.bn.bias.data.uniform_(-1, 1)
+    x = torch.randn(1, 19, 40, 1)
+    with torch.no_grad():
+        ref1 = mlp.layer0(x)
+        ref2 = mlp(x)
+    w, b = fused.fold_conv_bn(mlp.layer0)
+    torch.testing.assert_close(F.relu(torch.einsum("oc,bcnk->bonk", w, x) + b.view(1, -1, 1, 1)), ref1,
+                               rtol=1e-5, atol=1e-5)
+    # physical order: block 0 = [ch0,ch1,ch2, pad...], block 1.. = ch 3..18  (the SA layout)
+    phys = fused.sa_first_map(16)
+    packed, widths = fused.pack_stack(mlp, phys)
+    assert widths == [32, 32]
+
+    def run_layer(buf, nbi, nbo, act):            # act: (16*nbi, npix) physical channels
+        wts = buf[:nbo * nbi * 256].view(nbo, nbi, 64, 4)
+        bias = buf[nbo * nbi * 256:nbo * nbi * 256 + nbo * 16]
+        out = torch.zeros(16 * nbo, act.shape[1])
+        for o in range(nbo):
+            for lane in range(64):
+                row, g = lane % 16, lane // 16   # A operand: lane holds W[row][k = g] of each k-step
+                for m in range(nbi):
+                    for r in range(4):
+                        out[16 * o + row] += wts[o, m, lane, r] * act[16 * m + 4 * g + r]
+            out[16 * o:16 * o + 16] += bias[16 * o:16 * o + 16, None]
+        return F.relu(out)
+
+    act = torch.zeros(32, 40)
+    for p, c in enumerate(phys):
+        if c >= 0:
+            act[p] = x[0, c, :, 0]
+    n1 = fused.layer_floats(2, 2) if hasattr(fused, "layer_floats") else 2 * 2 * 256 + 32
+    h1 = run_layer(packed[:n1], 2, 2, act)
+    torch.testing.assert_close(h1[:24], ref1[0, :, :, 0], rtol=1e-5, atol=1e-5)
+    assert (h1[24:] == 0).all()                   # padded output channels stay exactly zero
+    h2 = run_layer(packed[n1:], 2, 2, h1)
+    torch.testing.assert_close(h2, ref2[0, :, :, 0], rtol=1e-5, atol=1e-5)
+
+
+def test_synthetic_generators():
+    from pwclonet_pylidarslam_amd import synthetic
+    a1, a2, q, t = synthetic.kitti_like_pair(5, 2048, 2)
+    b1, _, _, _ = synthetic.kitti_like_pair(5, 2048, 2)
+    assert a1.shape == (2, 2048, 4) and a1.dtype == np.float32 and np.array_equal(a1, b1)
+    # the reference's filter_pcd (kitti_odometry_dataset.py:149-172): no ground, 30 m box
+    for pc in (a1, a2):
+        assert (pc[..., 1] <= 1.1).all() and (np.abs(pc[..., 0]) < 30).all() and (np.abs(pc[..., 2]) < 30).all()
+        for cloud in pc:
+            assert len(np.unique(cloud[:, :3], axis=0)) == 2048          # duplicate free
+    np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-6)
+    u1, u2 = synthetic.uniform_pair(9, 512, 3)
+    assert u1.shape == (3, 512, 4) and not np.array_equal(u1, u2)
+
+
+def test_graph_wrappers_require_eval_mode():
+    from pwclonet_pylidarslam_amd.graphed import GraphedForward
+    from pwclonet_pylidarslam_amd.pwclonet import PWCLONet
+    net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device="cpu", scalar_last=False))
+    with pytest.raises(AssertionError):
+        GraphedForward(net.train())
+    net.eval()
+    assert net._fused is None
+    net.train()
+    assert net._fused is None
+
+
+WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+from pwclonet_pylidarslam_amd import dist_util
+rank, world = dist_util.init("gloo")
+lo, hi = dist_util.shard(65, rank, world)
+dist_util.fence(torch.device("cpu"))
+slow = dist_util.max_over_ranks(1.0 + rank)          # rank 1 is the slow one
+total = dist_util.sum_over_ranks(hi - lo)
+print("RESULT", rank, world, lo, hi, slow, total, flush=True)
+dist_util.finish()
+"""
+
+
+def test_two_rank_gloo_benchmark_plumbing(tmp_path):
+    """world_size 2 on CPU: disjoint shards covering the global batch, MAX-reduced step time."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29613")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    rows = sorted(l.split()[1:] for o in outs for l in o.splitlines() if l.startswith("RESULT"))
+    assert len(rows) == 2, outs
+    (r0, w0, lo0, hi0, s0, t0), (r1, w1, lo1, hi1, s1, t1) = rows
+    assert (w0, w1) == ("2", "2") and (lo0, hi0, lo1, hi1) == ("0", "33", "33", "65")
+    assert float(s0) == float(s1) == 2.0 and float(t0) == float(t1) == 65.0
