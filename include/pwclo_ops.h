@@ -115,6 +115,15 @@ void three_interpolate_grad_kernel_wrapper(int b, int c, int n, int m, const flo
 void knn_point_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz,
                               const float *new_xyz, int *idx, float *dist);
 
+/* Same result through an exact spatially pruned search (Morton-sorted candidate blocks with
+ * bounding boxes) when 512 <= n <= 16384: needs a caller-provided device workspace of
+ * knn_point_workspace_bytes(b, n) bytes (0 = not applicable: the exhaustive kernel is used and
+ * `workspace` may be NULL; also used when s < 512, where the build does not amortise).
+ * Bit-identical output to knn_point_kernel_wrapper. */
+long long knn_point_workspace_bytes(int b, int n);
+void knn_point_ws_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz,
+                                 const float *new_xyz, int *idx, float *dist, void *workspace);
+
 /* Replaces PWCLO_utils.py:42-63 (warp): out = q (x) (0,xyz) (x) q^-1 + t, scalar-first
  * quaternions, q^-1 = conj(q) / (|q|^2 + 1e-10).  xyz, out (b,3,n); q (b,4); t (b,3). */
 void quat_warp_kernel_wrapper(int b, int n, const float *xyz, const float *q, const float *t,

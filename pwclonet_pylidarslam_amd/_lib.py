@@ -33,6 +33,8 @@ SIGNATURES = {
     "three_interpolate_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
     "three_interpolate_grad_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
     "knn_point_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
+    "knn_point_workspace_bytes": ([_i, _i], ctypes.c_longlong),
+    "knn_point_ws_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F, _F], None),
     "quat_warp_kernel_wrapper": ([_i, _i, _F, _F, _F, _F], None),
     "sa_fused_kernel_wrapper": ([_i] * 8 + [_F] * 6, None),
     "furthest_point_sampling_xyz_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F], None),

@@ -229,3 +229,355 @@ extern "C" void knn_point_kernel_wrapper(int b, int n, int s, int nsample, const
   }
   check_launch("knn_point");
 }
+
+// =====================================================================================================
+// Spatially pruned exact search (n >= 512).
+//
+// knn_build_kernel (one workgroup per cloud): counting sort into (x-slab, z-bin) order, rows
+// (x, y, z, bits(original index)) in that order + one axis-aligned box per block of 64 consecutive rows.
+// knn_pruned_kernel (one wave per query): lower bound of t to every block box (64 boxes per
+// instruction), nearest block first to get a finite bound, then only blocks whose lower bound is
+// below the current bound.  Candidates carry their ORIGINAL index in the packed key, and a block is
+// skipped only when lb * (1 - 2^-18) >= bound (lb and t are evaluated with the same expression on
+// points inside the box, so that margin absorbs every rounding difference), hence the K smallest
+// (key, index) pairs -- and therefore the output -- are exactly those of the exhaustive scan.
+// =====================================================================================================
+namespace pwclo {
+
+constexpr int KB_THREADS = 1024;
+constexpr int KNN_MAX_SORT = 16384;  // u64 keys in LDS: 128 KiB
+
+__device__ __forceinline__ unsigned sortable(float f) {   // float -> unsigned with the same order
+  const unsigned u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unsortable(unsigned u) {
+  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+// Block-wide exclusive scan over KB_THREADS values (one per thread); returns the exclusive prefix.
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  __syncthreads();
+  return base + incl - v;
+}
+
+// Build (one workgroup per cloud, points in registers): a counting sort into (x-slab, z-bin) order.
+//   1. 1024-bin histogram of x -> slabs of ~n/nslab points (whole bins; exact balance is not needed);
+//   2. per slab, 1024/nslab z-bins; every slab is padded to a multiple of 64 rows so that no block of
+//      64 rows straddles two slabs;
+//   3. scatter rows (x, y, z, bits(original index)) with LDS cursors (order inside a bin is arbitrary:
+//      the query's result does not depend on it), inf rows in the padding;
+//   4. one bounding box per block.
+// 64 consecutive rows are then narrow in x (slab) and z (a few bins) and, lidar sweeps being 2.5-D,
+// in y: a query visits ~4 of 128 blocks at n = 8192 (Morton order: ~80).
+constexpr int KB_BINS = 1024;
+
+template <int R>
+__global__ __launch_bounds__(KB_THREADS) void knn_build_kernel(int n, int nslab, int nblk_max,
+                                                               const float *__restrict__ xyz,
+                                                               float4 *__restrict__ rows,
+                                                               float4 *__restrict__ boxes) {
+  __shared__ int hist[KB_BINS];      // x histogram, then slab of every x-bin
+  __shared__ int hist2[KB_BINS];     // (slab, z-bin) histogram, then row offset of every bin
+  __shared__ int cursor[KB_BINS];
+  __shared__ int wsum[KB_THREADS / 64];
+  __shared__ float red[4][KB_THREADS / 64];
+  __shared__ int slab_first[17], slab_count[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *pts = xyz + (size_t)blockIdx.x * n * 3;
+  const float INF = __int_as_float(0x7f800000);
+  const int zb = KB_BINS / nslab;                            // z-bins per slab
+
+  float px[R], py[R], pz[R];
+  float lox = INF, hix = -INF, loz = INF, hiz = -INF;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int k = r * KB_THREADS + tid;
+    px[r] = INF; py[r] = 0.f; pz[r] = 0.f;
+    if (k < n) {
+      px[r] = pts[k * 3 + 0]; py[r] = pts[k * 3 + 1]; pz[r] = pts[k * 3 + 2];
+      lox = fminf(lox, px[r]); hix = fmaxf(hix, px[r]);
+      loz = fminf(loz, pz[r]); hiz = fmaxf(hiz, pz[r]);
+    }
+  }
+  lox = wave_allreduce_f32(lox, [](float a, float b) { return fminf(a, b); });
+  hix = wave_allreduce_f32(hix, [](float a, float b) { return fmaxf(a, b); });
+  loz = wave_allreduce_f32(loz, [](float a, float b) { return fminf(a, b); });
+  hiz = wave_allreduce_f32(hiz, [](float a, float b) { return fmaxf(a, b); });
+  if (lane == 0) { red[0][wave] = lox; red[1][wave] = hix; red[2][wave] = loz; red[3][wave] = hiz; }
+  hist[tid] = 0; hist2[tid] = 0; cursor[tid] = 0;
+  __syncthreads();
+  for (int w = 0; w < KB_THREADS / 64; ++w) {
+    lox = fminf(lox, red[0][w]); hix = fmaxf(hix, red[1][w]);
+    loz = fminf(loz, red[2][w]); hiz = fmaxf(hiz, red[3][w]);
+  }
+  const float sx = hix > lox ? (float)KB_BINS / (hix - lox) : 0.f;
+  const float sz = hiz > loz ? (float)zb / (hiz - loz) : 0.f;
+
+  int bx[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    bx[r] = -1;
+    if (r * KB_THREADS + tid < n) {
+      bx[r] = min(max((int)((px[r] - lox) * sx), 0), KB_BINS - 1);
+      atomicAdd(&hist[bx[r]], 1);
+    }
+  }
+  __syncthreads();
+  {  // slab of every x-bin from the cumulative count at the start of the bin
+    const int before = block_exclusive_scan(hist[tid], wsum, tid);
+    const int target = (n + nslab - 1) / nslab;
+    hist[tid] = min(before / target, nslab - 1);
+  }
+  __syncthreads();
+  int b2[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    b2[r] = -1;
+    if (bx[r] >= 0) {
+      const int bz = min(max((int)((pz[r] - loz) * sz), 0), zb - 1);
+      b2[r] = hist[bx[r]] * zb + bz;
+      atomicAdd(&hist2[b2[r]], 1);
+    }
+  }
+  __syncthreads();
+  const int ex2 = block_exclusive_scan(hist2[tid], wsum, tid);   // rows before bin `tid`, unpadded
+  if ((tid % zb) == 0) slab_first[tid / zb] = ex2;               // unpadded start of each slab
+  if (tid == 0) slab_first[nslab] = n;
+  __syncthreads();
+  if (tid == 0) {                                               // padded slab starts (multiples of 64)
+    int start = 0;
+    for (int sl = 0; sl < nslab; ++sl) {
+      const int cnt = slab_first[sl + 1] - slab_first[sl];
+      slab_count[sl] = cnt;
+      wsum[sl] = start;                                          // reuse wsum[] as padded starts
+      start += (cnt + 63) / 64 * 64;
+    }
+    red[0][0] = __int_as_float(start);                           // rows in use (end of the last slab)
+  }
+  __syncthreads();
+  const int my_slab = tid / zb;
+  hist2[tid] = wsum[my_slab] + (ex2 - slab_first[my_slab]);      // row offset of bin `tid`
+  const int rows_used = __float_as_int(red[0][0]);
+  __syncthreads();
+  float4 *orow = rows + (size_t)blockIdx.x * nblk_max * 64;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (b2[r] >= 0) {
+      const int pos = hist2[b2[r]] + atomicAdd(&cursor[b2[r]], 1);
+      orow[pos] = make_float4(px[r], py[r], pz[r], __uint_as_float((unsigned)(r * KB_THREADS + tid)));
+    }
+  }
+  // padding rows: the tail of every slab and everything after the last slab
+  if (tid < 64) {
+    for (int sl = 0; sl < nslab; ++sl) {
+      const int beg = wsum[sl] + slab_count[sl];
+      const int end = wsum[sl] + (slab_count[sl] + 63) / 64 * 64;
+      if (beg + tid < end) orow[beg + tid] = make_float4(INF, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int p = rows_used + tid; p < nblk_max * 64; p += KB_THREADS) orow[p] = make_float4(INF, 0.f, 0.f, 0.f);
+  __syncthreads();   // rows written by this workgroup are read back below (never read before: no stale L1 line)
+  float4 *obox = boxes + (size_t)blockIdx.x * nblk_max * 2;
+  for (int blk = wave; blk < nblk_max; blk += KB_THREADS / 64) {
+    const float4 c = orow[blk * 64 + lane];
+    const bool valid = c.x != INF;
+    const unsigned big = 0xFFFFFFFFu;
+    const unsigned lx = wave_reduce_u32(valid ? sortable(c.x) : big, OpMinU32());
+    const unsigned ly = wave_reduce_u32(valid ? sortable(c.y) : big, OpMinU32());
+    const unsigned lz = wave_reduce_u32(valid ? sortable(c.z) : big, OpMinU32());
+    const unsigned hx = wave_reduce_u32(valid ? sortable(c.x) : 0u, OpMaxU32());
+    const unsigned hy = wave_reduce_u32(valid ? sortable(c.y) : 0u, OpMaxU32());
+    const unsigned hz = wave_reduce_u32(valid ? sortable(c.z) : 0u, OpMaxU32());
+    if (lane == 0) {
+      const bool any = lx != big;
+      obox[blk * 2 + 0] = any ? make_float4(unsortable(lx), unsortable(ly), unsortable(lz), 0.f)
+                              : make_float4(INF, INF, INF, 0.f);
+      obox[blk * 2 + 1] = any ? make_float4(unsortable(hx), unsortable(hy), unsortable(hz), 0.f)
+                              : make_float4(-INF, -INF, -INF, 0.f);
+    }
+  }
+}
+
+constexpr int KP_MAXR = 5;  // block boxes per lane: up to 320 blocks (16384 points + slab padding)
+
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_pruned_kernel(int nblk, int s, int K,
+                                                                    const float4 *__restrict__ rows,
+                                                                    const float4 *__restrict__ boxes,
+                                                                    const float *__restrict__ new_xyz,
+                                                                    int *__restrict__ idx,
+                                                                    float *__restrict__ dist) {
+  __shared__ u64 pools[KNN_WAVES][KNN_POOL];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * KNN_WAVES + wave;
+  if (q >= s) return;  // wave-uniform; no workgroup barrier below
+  const float INF = __int_as_float(0x7f800000);
+  const float *qp = new_xyz + ((size_t)b * s + q) * 3;
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  const float4 *crow = rows + (size_t)b * nblk * 64;
+  const float4 *cbox = boxes + (size_t)b * nblk * 2;
+  u64 *pool = pools[wave];
+
+  float lb[KP_MAXR];
+#pragma unroll
+  for (int r = 0; r < KP_MAXR; ++r) {
+    const int blk = r * 64 + lane;
+    float v = INF;
+    if (blk < nblk) {
+      const float4 l = cbox[blk * 2], h = cbox[blk * 2 + 1];
+      const float dx = fmaxf(fmaxf(l.x - qx, qx - h.x), 0.f);
+      const float dy = fmaxf(fmaxf(l.y - qy, qy - h.y), 0.f);
+      const float dz = fmaxf(fmaxf(l.z - qz, qz - h.z), 0.f);
+      v = ((dx * dx + dy * dy) + dz * dz) * 0.999996f;   // 1 - 2^-18: strictly conservative
+    }
+    lb[r] = v;                                            // empty boxes give inf (or NaN): never visited
+  }
+
+  float bound = INF;
+  unsigned bl = 0xFFFFFFFFu, bh = 0xFFFFFFFFu;
+  int cnt = 0;
+
+  auto fold = [&]() {  // fold min(cnt,64) pooled survivors into the sorted best list (see knn_kernel)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int c = cnt;
+    const u64 e = lane < c ? pool[lane] : KNN_EMPTY;
+    const u64 rest = (lane + 64 < c) ? pool[lane + 64] : KNN_EMPTY;
+    unsigned lo = (unsigned)e, hi = (unsigned)(e >> 32);
+    if (lane < c) hi = __float_as_uint(sqrtf(__uint_as_float(hi) + 1e-8f));
+    sort64<true>(lo, hi);
+    const u64 nv = ((u64)hi << 32) | lo, bv = ((u64)bh << 32) | bl;
+    const bool tk = nv < bv;
+    bl = tk ? lo : bl;
+    bh = tk ? hi : bh;
+    merge_stage<64, false>(bl, bh);
+    __builtin_amdgcn_wave_barrier();
+    const int left = c > 64 ? c - 64 : 0;
+    if (lane < left) pool[lane] = rest;
+    cnt = left;
+    const unsigned kbits = (unsigned)__builtin_amdgcn_readlane((int)bh, K - 1);
+    if (kbits != 0xFFFFFFFFu) {
+      const float key_k = __uint_as_float(kbits);
+      bound = (key_k * key_k) * 1.000001f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  auto process = [&](const float4 c) {                     // padding rows have x = inf -> t = inf
+    const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+    const float t = (dx * dx + dy * dy) + dz * dz;
+    const bool pass = t < bound;
+    const u64 mask = __ballot(pass);
+    if (mask != 0ull) {
+      if (pass) pool[cnt + mbcnt64(mask)] = ((u64)__float_as_uint(t) << 32) | (u64)__float_as_uint(c.w);
+      cnt = __builtin_amdgcn_readfirstlane(cnt + (int)__popcll(mask));
+      if (cnt >= 64) fold();
+    }
+  };
+
+  // nearest block first: a finite bound as early as possible
+  float best_lb = lb[0];
+  int best_blk = lane;
+#pragma unroll
+  for (int r = 1; r < KP_MAXR; ++r)
+    if (lb[r] < best_lb) { best_lb = lb[r]; best_blk = r * 64 + lane; }
+  const unsigned mlb = wave_reduce_u32(__float_as_uint(best_lb), OpMinU32());   // lb >= 0: bits order
+  const unsigned cand = __float_as_uint(best_lb) == mlb ? (unsigned)best_blk : 0xFFFFFFFFu;
+  const int first = (int)wave_reduce_u32(cand, OpMinU32());
+  process(crow[first * 64 + lane]);
+  if (cnt > 0 && bound == INF) fold();
+
+  // remaining blocks whose box can still hold a neighbour, 4 row loads in flight at a time (a wave
+  // is a chain of dependent steps; batching the loads is what hides the L2 latency)
+  constexpr int VB = 4;
+#pragma unroll
+  for (int r = 0; r < KP_MAXR; ++r) {
+    if (r * 64 >= nblk) break;
+    u64 todo = __ballot(lb[r] < bound && (r * 64 + lane) != first);
+    while (todo != 0ull) {
+      int blk[VB];
+      float lbv[VB];
+      float4 c[VB];
+#pragma unroll
+      for (int u = 0; u < VB; ++u) {
+        blk[u] = -1;
+        lbv[u] = INF;
+        if (todo != 0ull) {
+          const int i = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          blk[u] = r * 64 + i;
+          lbv[u] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(lb[r]), i));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < VB; ++u)
+        if (blk[u] >= 0) c[u] = crow[blk[u] * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < VB; ++u)
+        if (blk[u] >= 0 && lbv[u] < bound) process(c[u]);   // the bound may have tightened meanwhile
+    }
+  }
+  if (cnt > 0) fold();
+  if (lane < K) {
+    idx[((size_t)b * s + q) * K + lane] = (int)bl;
+    if (dist) dist[((size_t)b * s + q) * K + lane] = __uint_as_float(bh);
+  }
+}
+
+}  // namespace pwclo
+
+static int knn_slabs(int n) {            // ~ sqrt(#blocks), power of two in [2,16]
+  int nslab = 2;
+  while (nslab < 16 && nslab * nslab * 4 <= (n + 63) / 64) nslab <<= 1;
+  return nslab;
+}
+
+extern "C" long long knn_point_workspace_bytes(int b, int n) {
+  if (n < 512 || n > pwclo::KNN_MAX_SORT) return 0;       // exhaustive kernel: no workspace
+  const long long nblk = (n + 63) / 64 + knn_slabs(n);
+  return (long long)b * nblk * (64 * 16 + 32);
+}
+
+extern "C" void knn_point_ws_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz,
+                                            const float *new_xyz, int *idx, float *dist,
+                                            void *workspace) {
+  if (b <= 0 || s <= 0) return;
+  if (workspace == nullptr || knn_point_workspace_bytes(b, n) == 0 || s < 512) {
+    knn_point_kernel_wrapper(b, n, s, nsample, xyz, new_xyz, idx, dist);   // too few queries to amortise the build
+    return;
+  }
+  PWCLO_REQUIRE(nsample >= 1 && nsample <= 64, "knn_point: nsample=%d outside [1,64]", nsample);
+  PWCLO_REQUIRE(nsample <= n, "knn_point: nsample=%d exceeds the number of points n=%d", nsample, n);
+  PWCLO_REQUIRE(b <= 65535, "knn_point: b=%d exceeds the grid limit", b);
+  const int nslab = knn_slabs(n);
+  const int nblk = (n + 63) / 64 + nslab;
+  float4 *rows = reinterpret_cast<float4 *>(workspace);
+  float4 *boxes = rows + (size_t)b * nblk * 64;
+  const int regs = ceil_div(n, KB_THREADS);
+#define KB_CASE(RR)                                                                                   \
+  hipLaunchKernelGGL(knn_build_kernel<RR>, dim3(b), dim3(KB_THREADS), 0, current_stream(), n, nslab, nblk, \
+                     xyz, rows, boxes);
+  if (regs <= 1) { KB_CASE(1) }
+  else if (regs <= 2) { KB_CASE(2) }
+  else if (regs <= 4) { KB_CASE(4) }
+  else if (regs <= 8) { KB_CASE(8) }
+  else { KB_CASE(16) }
+#undef KB_CASE
+  hipLaunchKernelGGL(knn_pruned_kernel, dim3(ceil_div(s, KNN_WAVES), b), dim3(KNN_WAVES * 64), 0,
+                     current_stream(), nblk, s, nsample, rows, boxes, new_xyz, idx, dist);
+  check_launch("knn_point(pruned)");
+}

@@ -142,7 +142,7 @@ def group_points_grad(grad_out, idx, n):
 
 # ---- native replacements of pure-PyTorch ops (include/pwclo_ops.h section 2) ---------------------
 
-def knn_point(nsample, xyz, new_xyz, return_dist=False):
+def knn_point(nsample, xyz, new_xyz, return_dist=False, exhaustive=None):
     """Native kernel behind ``pytorch_utils.knn_point``.  xyz (B,N,3), new_xyz (B,S,3) ->
     idx (B,S,nsample) i32 ascending by distance (ties: lower index); optionally the keys."""
     _float(xyz, "xyz"); _float(new_xyz, "new_xyz"); _gpu(xyz, new_xyz)
@@ -150,8 +150,14 @@ def knn_point(nsample, xyz, new_xyz, return_dist=False):
     S = new_xyz.shape[1]
     idx = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
     dist = torch.empty((B, S, nsample), dtype=torch.float32, device=xyz.device) if return_dist else None
-    _lib.call("knn_point_kernel_wrapper", xyz.device, B, N, S, int(nsample), _p(xyz), _p(new_xyz), _p(idx),
-              _p(dist) if return_dist else 0)
+    ws_bytes = _lib.load().knn_point_workspace_bytes(B, N) if (exhaustive is not True and (S >= 512 or exhaustive is False)) else 0
+    if ws_bytes > 0:    # exact spatially pruned search (same output), needs scratch for the sorted rows
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=xyz.device)
+        _lib.call("knn_point_ws_kernel_wrapper", xyz.device, B, N, S, int(nsample), _p(xyz), _p(new_xyz),
+                  _p(idx), _p(dist) if return_dist else 0, _p(ws))
+    else:
+        _lib.call("knn_point_kernel_wrapper", xyz.device, B, N, S, int(nsample), _p(xyz), _p(new_xyz),
+                  _p(idx), _p(dist) if return_dist else 0)
     return (dist, idx) if return_dist else idx
 
 

@@ -203,7 +203,11 @@ def test_fused_forward_is_bitwise_deterministic_and_graph_safe(cuda):
     net.train()
     assert net._fused is None
     net.eval()
+    net.log_mode = "device"
     with torch.no_grad():
         c, log = net(x1, None, x2, None)
     torch.testing.assert_close(c, a, rtol=0, atol=5e-5)
     assert log["embedding_mask"].shape == (3, 2048)
+    _, lazy = net.prepare_fused()(x1, None, x2, None)      # fused path: same values, built on access
+    torch.testing.assert_close(lazy["embedding_mask"], log["embedding_mask"], rtol=1e-4, atol=1e-6)
+    assert torch.equal(lazy["point_cloud"], log["point_cloud"])

@@ -248,3 +248,21 @@ def test_quat_warp(cuda):
     tt = torch.tensor([[[1.0], [2.0], [3.0]]])
     got = E.quat_warp(one.to(cuda), qz.to(cuda), tt.to(cuda)).cpu().flatten()
     torch.testing.assert_close(got, torch.tensor([1.0, 3.0, 3.0]), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("k,n,s", [(32, 8192, 2048), (6, 2048, 2048), (16, 1024, 256), (1, 513, 77),
+                                   (64, 16384, 100), (8, 700, 1500)])
+def test_knn_pruned_equals_exhaustive(cuda, k, n, s):
+    """The Morton-block pruned search (512 <= n <= 16384) returns exactly what the exhaustive
+    kernel returns, on KITTI-shaped (strongly non-uniform) clouds and with duplicated points."""
+    pc1, _, _, _ = synthetic.kitti_like_pair(90 + k, 8192, 2)
+    base = torch.from_numpy(np.ascontiguousarray(pc1[:, :, :3]))
+    reps = (n + 8191) // 8192
+    x = base.repeat(1, reps, 1)[:, :n].contiguous()          # n > 8192: exact duplicates
+    q = (x[:, torch.randperm(n, generator=torch.Generator().manual_seed(k))[:s] % n] + 0.05).contiguous() \
+        if s <= n else (torch.rand(2, s, 3) * 40 - 20)
+    x, q = x.to(cuda), q.to(cuda)
+    d1, i1 = E.knn_point(k, x, q, return_dist=True)
+    d0, i0 = E.knn_point(k, x, q, return_dist=True, exhaustive=True)
+    assert torch.equal(i1, i0)
+    assert torch.equal(d1, d0)
