@@ -150,6 +150,10 @@ void sa_fused_kernel_wrapper(int b, int n, int s, int k, int c_feat, int c1, int
 void furthest_point_sampling_xyz_kernel_wrapper(int b, int n, int m, const float *dataset,
                                                 float *temp, int *idxs, float *new_xyz);
 
+/* Input adapter (pwclo_net.py:125-126 and the siamese batching): xyz_f1, xyz_f2 (b,3,n) channel-major
+ * -> out (2b,n,3) point-major, frame 1 first. */
+void ingest_pairs_kernel_wrapper(int b, int n, const float *xyz_f1, const float *xyz_f2, float *out);
+
 /* quat_warp_kernel_wrapper on point-major clouds: xyz, out (b,n,3). */
 void quat_warp_pm_kernel_wrapper(int b, int n, const float *xyz, const float *q, const float *t,
                                  float *out);

@@ -13,12 +13,12 @@
 // The only materialised intermediate is cv_a1's 64-channel per-pixel feature (written once, read
 // once); the reference materialises > 10 (B,C,S,K) tensors for the same result.
 #include <math.h>
+#include <stdlib.h>
 
 #include "mlp_core.hpp"
 
 namespace pwclo {
 
-constexpr int FL_WAVES = 8;
 
 // ---- shared prologue pieces ----------------------------------------------------------------------
 
@@ -83,7 +83,7 @@ __device__ __forceinline__ void softmax_weighted_sum(f32x4 (&res)[P], const f32x
   const int pix_per_cloud = (S_) * (KP_);                                                           \
   const int tiles_per_cloud = (pix_per_cloud + TILE - 1) / TILE;                                    \
   const int ntiles = (B_) * tiles_per_cloud;                                                        \
-  for (int t = blockIdx.x * FL_WAVES + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * FL_WAVES)
+  for (int t = blockIdx.x * W + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * W)
 
 // ---- set-upconv: PointnetFPModulePWCLONet, knn branch up to the max (pointnet2_modules.py:479-506) --
 struct UpconvArgs {
@@ -94,15 +94,17 @@ struct UpconvArgs {
   const float *w;       // packed [64 feat | diff block] -> 128 -> 64
   float *out;           // (B,S,64)
   int B, N, S, K;
+  int stagger;
 };
 
-template <int KP, int P>
-__global__ __launch_bounds__(FL_WAVES * 64) void upconv_kernel(UpconvArgs a) {
+template <int KP, int P, int W>
+__global__ __launch_bounds__(W * 64) void upconv_kernel(UpconvArgs a) {
   constexpr int NBI = 5, B1 = 8, B2 = 4;
   constexpr int W1 = layer_floats(NBI, B1), W2 = layer_floats(B1, B2);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2);
   __syncthreads();
+  stagger_start(threadIdx.x >> 6, (NBI * B1 + B1 * B2) * 4 * P, a.stagger);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   PWCLO_TILE_LOOP(KP, P, a.S, a.B) {
     const int b = t / tiles_per_cloud;
@@ -151,10 +153,11 @@ struct PointwiseArgs {
   const float *w;       // packed layers
   float *out;           // (B,S,16*BOUT)
   int B, S;
+  int stagger;
 };
 
-template <int NB0, int NB1, int NB2, int B1, int B2 /*0 = single layer*/, int P>
-__global__ __launch_bounds__(FL_WAVES * 64) void pointwise_kernel(PointwiseArgs a) {
+template <int NB0, int NB1, int NB2, int B1, int B2 /*0 = single layer*/, int P, int W>
+__global__ __launch_bounds__(W * 64) void pointwise_kernel(PointwiseArgs a) {
   constexpr int NBI = NB0 + NB1 + NB2;
   constexpr int W1 = layer_floats(NBI, B1);
   constexpr int W2 = B2 > 0 ? layer_floats(B1, B2) : 0;
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(FL_WAVES * 64) void pointwise_kernel(PointwiseArgs 
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2);
   __syncthreads();
+  stagger_start(threadIdx.x >> 6, (NBI * B1 + B1 * B2) * 4 * P, a.stagger);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   PWCLO_TILE_LOOP(1, P, a.S, a.B) {
     const int b = t / tiles_per_cloud;
@@ -212,16 +216,18 @@ struct CVArgs {
   float *pix;           // a1: out (B,S*KP,64); a2: in (same)
   float *out;           // a2 / b: (B,S,64)
   int B, N, S, K;
+  int stagger;
 };
 
 // a1: [geo | centre feat (CB blocks) | gathered feat (CB blocks)] -> 128 -> 64 -> 64, stored per pixel.
-template <int CB, int KP, int P>
-__global__ __launch_bounds__(FL_WAVES * 64) void cv_a1_kernel(CVArgs a) {
+template <int CB, int KP, int P, int W>
+__global__ __launch_bounds__(W * 64) void cv_a1_kernel(CVArgs a) {
   constexpr int NBI = 1 + 2 * CB, B1 = 8, B2 = 4, B3 = 4, C = 16 * CB;
   constexpr int W1 = layer_floats(NBI, B1), W2 = layer_floats(B1, B2), W3 = layer_floats(B2, B3);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2 + W3);
   __syncthreads();
+  stagger_start(threadIdx.x >> 6, (NBI * B1 + B1 * B2 + B2 * B3) * 4 * P, a.stagger);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   PWCLO_TILE_LOOP(KP, P, a.S, a.B) {
     const int b = t / tiles_per_cloud;
@@ -255,12 +261,13 @@ __global__ __launch_bounds__(FL_WAVES * 64) void cv_a1_kernel(CVArgs a) {
 }
 
 // a2: enc = mlp_conv_xyz_1(geo); w = softmax_k(mlp2_convs([enc | feat])); out = sum_k w * feat.
-template <int KP, int P>
-__global__ __launch_bounds__(FL_WAVES * 64) void cv_a2_kernel(CVArgs a) {
+template <int KP, int P, int W>
+__global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats(8, 8), W2 = layer_floats(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, WX + W1 + W2);
   __syncthreads();
+  stagger_start(threadIdx.x >> 6, (4 + 64 + 32) * 4 * P, a.stagger);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   PWCLO_TILE_LOOP(KP, P, a.S, a.B) {
     const int b = t / tiles_per_cloud;
@@ -307,13 +314,14 @@ __global__ __launch_bounds__(FL_WAVES * 64) void cv_a2_kernel(CVArgs a) {
 
 // b: enc2 = mlp_conv_xyz_2(geo'); w = softmax_k(mlp3_convs([enc2 | centre feat | gathered first]));
 //    out = sum_k w * gathered first.  Candidates = the frame-1 points themselves (N == S).
-template <int CB, int KP, int P>
-__global__ __launch_bounds__(FL_WAVES * 64) void cv_b_kernel(CVArgs a) {
+template <int CB, int KP, int P, int W>
+__global__ __launch_bounds__(W * 64) void cv_b_kernel(CVArgs a) {
   constexpr int NBI = 4 + CB + 4, C = 16 * CB;
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats(NBI, 8), W2 = layer_floats(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, WX + W1 + W2);
   __syncthreads();
+  stagger_start(threadIdx.x >> 6, (4 + NBI * 8 + 32) * 4 * P, a.stagger);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   PWCLO_TILE_LOOP(KP, P, a.S, a.B) {
     const int b = t / tiles_per_cloud;
@@ -495,17 +503,25 @@ __global__ __launch_bounds__(64 * MP_PARTS) void pose_head_kernel(PoseHeadArgs a
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------------
-template <typename Kern, typename Args>
+static int fl_tuning(const char *name, int dflt) {   // PWCLO_FL_<NAME> overrides (experiments)
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <int W, typename Kern, typename Args>
 static void launch_persistent(Kern kern, bool &attr_set, int lds_bytes, long long ntiles, const Args &a) {
   if (lds_bytes > 64 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
-  const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
-  long long grid = (ntiles + FL_WAVES - 1) / FL_WAVES;
-  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  // Workgroups beyond one resident set queue behind it; >1 "rounds" keeps the kernel balanced when
+  // part of the chip is held by another stream's kernels (e.g. the other in-flight batch's FPS).
+  static const int rounds = fl_tuning("PWCLO_FL_ROUNDS", 1);
+  const int per_cu = (lds_bytes > 80 * 1024 || W > 8) ? 1 : 2;
+  long long grid = (ntiles + W - 1) / W;
+  if (grid > 256LL * per_cu * rounds) grid = 256LL * per_cu * rounds;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FL_WAVES * 64), lds_bytes, current_stream(), a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W * 64), lds_bytes, current_stream(), a);
 }
 
 static long long tiles_of(int b, int s, int kp, int p) {
@@ -521,10 +537,12 @@ extern "C" void upconv_fused_kernel_wrapper(int b, int n, int s, int k, const fl
                                             const float *packed_w, float *out) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 8, "upconv_fused: nsample=%d outside [1,8]", k);
-  UpconvArgs a{xyz2, xyz1, feat1, idx, packed_w, out, b, n, s, k};
-  static bool attr = false;
-  launch_persistent(upconv_kernel<8, 2>, attr, 4 * (layer_floats(5, 8) + layer_floats(8, 4)),
-                    tiles_of(b, s, 8, 2), a);
+  UpconvArgs a{xyz2, xyz1, feat1, idx, packed_w, out, b, n, s, k, fl_tuning("PWCLO_FL_STAGGER", 0)};
+  static bool attr = false, attr1 = false;
+  static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);
+  constexpr int lds = 4 * (layer_floats(5, 8) + layer_floats(8, 4));
+  if (wide) launch_persistent<16>(upconv_kernel<8, 1, 16>, attr1, lds, tiles_of(b, s, 8, 1), a);
+  else launch_persistent<8>(upconv_kernel<8, 2, 8>, attr, lds, tiles_of(b, s, 8, 2), a);
   check_launch("upconv_fused");
 }
 
@@ -532,14 +550,17 @@ extern "C" void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int
                                                const float *src0, const float *src1, const float *src2,
                                                const float *packed_w, float *out) {
   if (b <= 0 || s <= 0) return;
-  PointwiseArgs a{{src0, src1, src2}, packed_w, out, b, s};
+  PointwiseArgs a{{src0, src1, src2}, packed_w, out, b, s, fl_tuning("PWCLO_FL_STAGGER", 0)};
 #define PW_CASE(C0, C1, C2, A1, A2)                                                                 \
   if (c0 == C0 && c1 == C1 && c2 == C2 && w1 == A1 && w2 == A2) {                                   \
-    static bool attr = false;                                                                       \
+    static bool attr = false, attr1 = false;                                                        \
+    static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);                                          \
     constexpr int NBI = (C0 + C1 + C2) / 16;                                                        \
     constexpr int lds = 4 * (layer_floats(NBI, A1 / 16) + (A2 > 0 ? layer_floats(A1 / 16, A2 / 16) : 0)); \
-    launch_persistent(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 2>, attr, lds,   \
-                      tiles_of(b, s, 1, 2), a);                                                     \
+    if (wide) launch_persistent<16>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 16>, \
+                                    attr1, lds, tiles_of(b, s, 1, 1), a);                           \
+    else launch_persistent<8>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 2, 8>, attr, lds, \
+                              tiles_of(b, s, 1, 2), a);                                             \
     check_launch("pointwise_fused");                                                                \
     return;                                                                                         \
   }
@@ -561,13 +582,15 @@ extern "C" void cv_fused_a1_kernel_wrapper(int b, int n, int s, int k, int c, co
                                            const int *idx, const float *packed_w, float *pix) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a1: nsample_q=%d outside [1,32]", k);
-  CVArgs a{xyz1, feat1, xyz2, feat2, idx, packed_w, pix, nullptr, b, n, s, k};
+  CVArgs a{xyz1, feat1, xyz2, feat2, idx, packed_w, pix, nullptr, b, n, s, k, fl_tuning("PWCLO_FL_STAGGER", 0)};
   const int kp = k > 16 ? 32 : (k > 8 ? 16 : 8);
 #define A1_CASE(C, KP)                                                                              \
   if (c == C && kp == KP) {                                                                         \
-    static bool attr = false;                                                                       \
+    static bool attr = false, attr1 = false;                                                        \
+    static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);                                          \
     constexpr int lds = 4 * (layer_floats(1 + 2 * (C / 16), 8) + layer_floats(8, 4) + layer_floats(4, 4)); \
-    launch_persistent(cv_a1_kernel<C / 16, KP, 2>, attr, lds, tiles_of(b, s, KP, 2), a);            \
+    if (wide && KP <= 16) launch_persistent<16>(cv_a1_kernel<C / 16, KP, 1, 16>, attr1, lds, tiles_of(b, s, KP, 1), a); \
+    else launch_persistent<8>(cv_a1_kernel<C / 16, KP, 2, 8>, attr, lds, tiles_of(b, s, KP, 2), a);  \
     check_launch("cv_fused_a1");                                                                    \
     return;                                                                                         \
   }
@@ -581,13 +604,17 @@ extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const flo
                                            const float *pix, float *out) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a2: nsample_q=%d outside [1,32]", k);
-  CVArgs a{xyz1, nullptr, xyz2, nullptr, idx, packed_w, const_cast<float *>(pix), out, b, n, s, k};
+  CVArgs a{xyz1, nullptr, xyz2, nullptr, idx, packed_w, const_cast<float *>(pix), out, b, n, s, k,
+           fl_tuning("PWCLO_FL_STAGGER", 0)};
   const int kp = k > 16 ? 32 : (k > 8 ? 16 : 8);
   constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(8, 8) + layer_floats(8, 4));
-  static bool attr32 = false, attr16 = false, attr8 = false;
-  if (kp == 32) launch_persistent(cv_a2_kernel<32, 2>, attr32, lds, tiles_of(b, s, 32, 2), a);
-  else if (kp == 16) launch_persistent(cv_a2_kernel<16, 2>, attr16, lds, tiles_of(b, s, 16, 2), a);
-  else launch_persistent(cv_a2_kernel<8, 2>, attr8, lds, tiles_of(b, s, 8, 2), a);
+  static bool attr32 = false, attr16 = false, attr8 = false, attr16w = false, attr8w = false;
+  static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);
+  if (kp == 32) launch_persistent<8>(cv_a2_kernel<32, 2, 8>, attr32, lds, tiles_of(b, s, 32, 2), a);
+  else if (kp == 16 && wide) launch_persistent<16>(cv_a2_kernel<16, 1, 16>, attr16w, lds, tiles_of(b, s, 16, 1), a);
+  else if (kp == 16) launch_persistent<8>(cv_a2_kernel<16, 2, 8>, attr16, lds, tiles_of(b, s, 16, 2), a);
+  else if (wide) launch_persistent<16>(cv_a2_kernel<8, 1, 16>, attr8w, lds, tiles_of(b, s, 8, 1), a);
+  else launch_persistent<8>(cv_a2_kernel<8, 2, 8>, attr8, lds, tiles_of(b, s, 8, 2), a);
   check_launch("cv_fused_a2");
 }
 
@@ -596,12 +623,14 @@ extern "C" void cv_fused_b_kernel_wrapper(int b, int s, int k, int c, const floa
                                           const float *packed_w, float *out) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 4, "cv_fused_b: nsample=%d outside [1,4]", k);
-  CVArgs a{xyz1, feat1, xyz1, first, idx, packed_w, nullptr, out, b, s, s, k};
+  CVArgs a{xyz1, feat1, xyz1, first, idx, packed_w, nullptr, out, b, s, s, k, fl_tuning("PWCLO_FL_STAGGER", 0)};
 #define B_CASE(C)                                                                                   \
   if (c == C) {                                                                                     \
-    static bool attr = false;                                                                       \
+    static bool attr = false, attr1 = false;                                                        \
+    static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);                                          \
     constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(8 + C / 16, 8) + layer_floats(8, 4)); \
-    launch_persistent(cv_b_kernel<C / 16, 4, 2>, attr, lds, tiles_of(b, s, 4, 2), a);               \
+    if (wide) launch_persistent<16>(cv_b_kernel<C / 16, 4, 1, 16>, attr1, lds, tiles_of(b, s, 4, 1), a); \
+    else launch_persistent<8>(cv_b_kernel<C / 16, 4, 2, 8>, attr, lds, tiles_of(b, s, 4, 2), a);     \
     check_launch("cv_fused_b");                                                                     \
     return;                                                                                         \
   }

@@ -7,6 +7,8 @@
 // by ONE kernel whose HBM traffic is the algorithmic minimum: indices + gathered rows in,
 // (B,S,Cout) out.  Feature tensors are point-major (B,N,C) so a neighbour's channels are one
 // contiguous row (16-byte gathers).  See mlp_core.hpp for the register/MFMA layout.
+#include <stdlib.h>
+
 #include "mlp_core.hpp"
 
 namespace pwclo {
@@ -19,6 +21,7 @@ struct SAArgs {
   const float *w;        // packed layers 1..3 (fused.py: pack_layer), consecutive
   float *out;            // (B,S,16*B3)
   int B, N, S, K;
+  int stagger;
 };
 
 constexpr int SA_WAVES = 8;
@@ -35,6 +38,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_kernel(SAArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2 + W3);
   __syncthreads();
+  stagger_start(threadIdx.x >> 6, (NBI * B1 + B1 * B2 + B2 * B3) * 4 * P, a.stagger);
 
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const int wave = threadIdx.x >> 6;
@@ -112,9 +116,11 @@ static void launch_sa(const SAArgs &a) {
   }
   const long long pix = (long long)a.S * KP;
   const long long ntiles = (long long)a.B * ((pix + 16 * P - 1) / (16 * P));
+  static int rounds = -1;
+  if (rounds < 0) { const char *e = getenv("PWCLO_FL_ROUNDS"); rounds = e ? atoi(e) : 1; }
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   long long grid = (ntiles + SA_WAVES - 1) / SA_WAVES;
-  if (grid > 256 * per_cu) grid = 256 * per_cu;      // persistent: one or two workgroups per CU
+  if (grid > 256LL * per_cu * rounds) grid = 256LL * per_cu * rounds;   // persistent workgroups
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SA_WAVES * 64), lds_bytes, current_stream(), a);
 }
 
@@ -128,7 +134,9 @@ extern "C" void sa_fused_kernel_wrapper(int b, int n, int s, int k, int c_feat, 
                                         const int *idx, const float *packed_w, float *out) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "sa_fused: nsample=%d outside [1,32]", k);
-  SAArgs a{xyz, new_xyz, feat, idx, packed_w, out, b, n, s, k};
+  static int stagger = -1;
+  if (stagger < 0) { const char *e = getenv("PWCLO_FL_STAGGER"); stagger = e ? atoi(e) : 0; }
+  SAArgs a{xyz, new_xyz, feat, idx, packed_w, out, b, n, s, k, stagger};
   const int kp = k > 16 ? 32 : 16;
 #define SA_CASE(CF, A1, A2, A3, KP, XYZ)                                                          \
   if (c_feat == CF && c1 == A1 && c2 == A2 && c3 == A3 && kp == KP) {                             \

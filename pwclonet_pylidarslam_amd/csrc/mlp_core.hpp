@@ -36,40 +36,63 @@ __device__ __forceinline__ void stage_weights(float *lds, const float *__restric
 }
 
 // One layer for P pixel blocks.  `w` points at the layer's packed weights in LDS.
+// The (output block o, input block m) operand tiles are walked as ONE flat sequence with the next
+// tile's ds_read_b128 issued before the current tile's 4*P MFMAs (register double buffer, 8 VGPRs),
+// so the LDS latency sits under matrix work; a sched_barrier per tile keeps the scheduler from
+// hoisting every later read as well (which spilled).
 template <int NBI, int NBO, int P, bool RELU>
 __device__ __forceinline__ void mlp_layer(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
                                           const float *w, int lane) {
   const int g = lane >> 4;
   const float *bias = w + NBO * NBI * 256;
+  const float *wl = w + lane * 4;
+  f32x4 wv = *reinterpret_cast<const f32x4 *>(wl);
+  f32x4 acc[P];
 #pragma unroll
-  for (int o = 0; o < NBO; ++o) {
-    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 16 * o + 4 * g);
-    f32x4 acc[P];
+  for (int t = 0; t < NBO * NBI; ++t) {
+    const int o = t / NBI, m = t % NBI;
+    f32x4 wnext = wv;
+    if (t + 1 < NBO * NBI) wnext = *reinterpret_cast<const f32x4 *>(wl + (t + 1) * 256);
+    if (m == 0) {
+      const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 16 * o + 4 * g);
 #pragma unroll
-    for (int p = 0; p < P; ++p) acc[p] = bv;
-#pragma unroll
-    for (int m = 0; m < NBI; ++m) {
-      const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + ((o * NBI + m) * 64 + lane) * 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[r], in[m][p][r], acc[p], 0, 0, 0);
-      }
+      for (int p = 0; p < P; ++p) acc[p] = bv;
     }
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      if (RELU) {
-        f32x4 v = acc[p];
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        out[o][p] = v;
-      } else {
-        out[o][p] = acc[p];
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[r], in[m][p][r], acc[p], 0, 0, 0);
+    }
+    if (m == NBI - 1) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (RELU) {
+          f32x4 v = acc[p];
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          out[o][p] = v;
+        } else {
+          out[o][p] = acc[p];
+        }
       }
     }
-    // Keep the unrolled output blocks in program order: without this the scheduler hoists the
-    // LDS operand reads of every later block (4 VGPRs each) and spills.
+    wv = wnext;
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- start-up stagger ------------------------------------------------------------------------------
+// All waves of a workgroup start their first tile together, and because they share one matrix pipe
+// per SIMD they stay in phase: every tile's gather prologue (two dependent global loads) and
+// epilogue then run with the pipe idle (measured: 66-77 % SQ_VALU_MFMA_BUSY).  Delaying the j-th
+// wave of a SIMD by j wave-shares of MFMA time once, at kernel start, puts one wave's
+// prologue/epilogue under the other waves' MFMAs for the rest of the kernel.  Waves w, w+4, w+8,
+// ... share a SIMD (cyclic placement); purely a performance device -- no correctness dependence.
+__device__ __forceinline__ void stagger_start(int wave, int mfma_per_tile, int enable) {
+  const int j = wave >> 2;
+  if (enable && j > 0) {
+    const int naps = (j * mfma_per_tile * 32 + 4095) / 4096;
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 clocks
   }
 }
 

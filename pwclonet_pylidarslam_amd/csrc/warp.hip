@@ -42,9 +42,34 @@ __global__ __launch_bounds__(256) void quat_warp_kernel(int n, const float *__re
   dst[sx + 2 * st] = r.z + t[b * 3 + 2];
 }
 
+// Input adapter of the fused pipeline: two (B,3,N) channel-major clouds (what PWCLONet.forward
+// receives, pwclo_net.py:125-126) -> one point-major (2B,N,3) batch (frame 1 first).  Replaces
+// torch.cat + permute + contiguous (three passes) by one.
+__global__ __launch_bounds__(256) void ingest_pairs_kernel(int bsz, int n, const float *__restrict__ f1,
+                                                           const float *__restrict__ f2,
+                                                           float *__restrict__ out) {
+  const int b = blockIdx.y;               // 0 .. 2*bsz-1
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const float *src = (b < bsz ? f1 + (size_t)b * 3 * n : f2 + (size_t)(b - bsz) * 3 * n);
+  float *dst = out + ((size_t)b * n + j) * 3;
+  dst[0] = src[j];
+  dst[1] = src[n + j];
+  dst[2] = src[2 * n + j];
+}
+
 }  // namespace pwclo
 
 using namespace pwclo;
+
+extern "C" void ingest_pairs_kernel_wrapper(int b, int n, const float *xyz_f1, const float *xyz_f2,
+                                            float *out) {
+  if (b <= 0 || n <= 0) return;
+  PWCLO_REQUIRE(2 * b <= 65535, "ingest_pairs: b=%d exceeds the grid limit", b);
+  hipLaunchKernelGGL(ingest_pairs_kernel, dim3(ceil_div(n, 256), 2 * b), dim3(256), 0, current_stream(), b, n,
+                     xyz_f1, xyz_f2, out);
+  check_launch("ingest_pairs");
+}
 
 extern "C" void quat_warp_kernel_wrapper(int b, int n, const float *xyz, const float *q,
                                          const float *t, float *out) {

@@ -348,8 +348,10 @@ class FusedPWCLONet:
     @torch.no_grad()
     def __call__(self, xyz_f1, xyz_f2, return_intermediates=False):
         """xyz_f1, xyz_f2 (B,3,N) -> pose_params (B,4,7) [+ dict of point-major intermediates]."""
-        B = xyz_f1.shape[0]
-        x = torch.cat((xyz_f1, xyz_f2), dim=0).permute(0, 2, 1).contiguous()     # (2B,N,3)
+        B, _, N0 = xyz_f1.shape
+        x = torch.empty((2 * B, N0, 3), dtype=torch.float32, device=xyz_f1.device)  # both frames, point-major
+        _lib.call("ingest_pairs_kernel_wrapper", x.device, B, N0, _p(xyz_f1.contiguous()),
+                  _p(xyz_f2.contiguous()), _p(x))
         f = None
         lv = []
         for fsa, (npoint, nsample) in zip(self.sa, self.sa_cfg):

@@ -23,7 +23,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def header_functions():
     text = open(os.path.join(ROOT, "include", "pwclo_ops.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return re.findall(r"\b(?:void|int|const char \*|void \*)\s*\*?\s*(\w+)\s*\(", text)
+    return re.findall(r"\b(?:void|int|long long|const char \*|void \*)\s*\*?\s*(\w+)\s*\(", text)
 
 
 def test_library_exports_every_declared_symbol():
