@@ -117,7 +117,7 @@ static void launch_sa(const SAArgs &a) {
   const long long pix = (long long)a.S * KP;
   const long long ntiles = (long long)a.B * ((pix + 16 * P - 1) / (16 * P));
   static int rounds = -1;
-  if (rounds < 0) { const char *e = getenv("PWCLO_FL_ROUNDS"); rounds = e ? atoi(e) : 1; }
+  if (rounds < 0) { const char *e = getenv("PWCLO_FL_ROUNDS"); rounds = e ? atoi(e) : 2; }
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   long long grid = (ntiles + SA_WAVES - 1) / SA_WAVES;
   if (grid > 256LL * per_cu * rounds) grid = 256LL * per_cu * rounds;   // persistent workgroups

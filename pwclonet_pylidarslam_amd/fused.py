@@ -302,6 +302,49 @@ class FusedPoseHead:
 
 # ---- whole network --------------------------------------------------------------------------------------
 
+class _Branches:
+    """Fork/join helper for the captured forward: side streams + events become graph edges, so
+    independent branches (the FPS chain vs. the per-level neighbour search / MLPs; the two
+    set-upconvs vs. the warp -> cost-volume chain) may overlap on the GPU.  Only used while a
+    hipGraph is being captured: every tensor created meanwhile is kept alive until the forward
+    returns, so the graph's memory pool cannot hand a buffer of one branch to another."""
+
+    def __init__(self, device, enabled):
+        self.on = enabled
+        self.main = torch.cuda.current_stream(device)
+        self.side = [torch.cuda.Stream(device=device) for _ in range(3)] if enabled else []
+        self.keep = []
+
+    def hold(self, *tensors):
+        if self.on:
+            self.keep.extend(tensors)
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    def fork(self, k):
+        """Context: run the body on side stream k, after everything queued on main so far."""
+        if not self.on:
+            return torch.cuda.stream(self.main)
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side[k].wait_event(ev)
+        return torch.cuda.stream(self.side[k])
+
+    def mark(self, k):
+        """Event at the current tail of side stream k (or None when branching is off)."""
+        if not self.on:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.side[k])
+        return ev
+
+    def wait(self, ev):
+        if ev is not None:
+            self.main.wait_event(ev)
+
+    def join(self, k):
+        self.wait(self.mark(k))
+
+
 class FusedPWCLONet:
     """Eval-mode forward of a ``PWCLONet`` on the fused kernels (point-major activations).
 
@@ -314,6 +357,8 @@ class FusedPWCLONet:
     def __init__(self, net):
         from .pwclonet import PWCLO_utils as pw
         assert not net.training, "the fused path implements eval-mode semantics"
+        import os
+        self.branch = os.environ.get("PWCLO_BRANCH", "1") != "0"   # fork/join streams under graph capture
         self.pw = pw
         self.sa = [FusedSA(m) for m in (net.psa_1, net.psa_2, net.psa_3, net.psa_4)]
         self.sa_cfg = [(m.npoint, m.nsample) for m in (net.psa_1, net.psa_2, net.psa_3, net.psa_4)]
@@ -334,12 +379,16 @@ class FusedPWCLONet:
                      head=FusedPoseHead(m.pose_calculator), last=m.last_pose_estimation)
             self.pwr.append(d)
 
-    def _refine(self, d, row, pose, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev):
-        idx_up = knn(8, x1_prev, x1)
-        up_feat = d["up_f"](x1, x1_prev, f1, emb_prev, idx_up)
-        up_mask = d["up_m"](x1, x1_prev, f1, mask_prev, idx_up)
-        warped = quat_warp_pm(x1, q_prev, t_prev)
-        resid = d["cv"](warped, f1, x2, f2)
+    def _refine(self, br, d, row, pose, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev):
+        idx_up = br.hold(knn(8, x1_prev, x1))
+        with br.fork(1):        # set-upconv of the features ...
+            up_feat = br.hold(d["up_f"](x1, x1_prev, f1, emb_prev, idx_up))
+        with br.fork(2):        # ... and of the mask are independent of the warp -> cost-volume chain
+            up_mask = br.hold(d["up_m"](x1, x1_prev, f1, mask_prev, idx_up))
+        warped = br.hold(quat_warp_pm(x1, q_prev, t_prev))
+        resid = br.hold(d["cv"](warped, f1, x2, f2))
+        br.join(1)
+        br.join(2)
         emb = d["pred_f"](f1, resid, up_feat)
         mask = up_mask if d["last"] else d["pred_m"](up_mask, emb, f1)
         q, t = d["head"](emb, mask, pose, row, q_prev, t_prev)
@@ -349,15 +398,26 @@ class FusedPWCLONet:
     def __call__(self, xyz_f1, xyz_f2, return_intermediates=False):
         """xyz_f1, xyz_f2 (B,3,N) -> pose_params (B,4,7) [+ dict of point-major intermediates]."""
         B, _, N0 = xyz_f1.shape
+        br = _Branches(xyz_f1.device, self.branch and torch.cuda.is_current_stream_capturing())
         x = torch.empty((2 * B, N0, 3), dtype=torch.float32, device=xyz_f1.device)  # both frames, point-major
         _lib.call("ingest_pairs_kernel_wrapper", x.device, B, N0, _p(xyz_f1.contiguous()),
                   _p(xyz_f2.contiguous()), _p(x))
+        # The sampling chain of all four levels depends only on the input cloud: it runs ahead on its
+        # own branch while the main branch does neighbour search + MLP level by level.
+        samples, ready = [], []
+        with br.fork(0):
+            src = x
+            for npoint, _ in self.sa_cfg:
+                _, src = br.hold(*fps_with_xyz(src, npoint))
+                samples.append(src)
+                ready.append(br.mark(0))
         f = None
         lv = []
-        for fsa, (npoint, nsample) in zip(self.sa, self.sa_cfg):
-            _, new_x = fps_with_xyz(x, npoint)
-            idx = knn(nsample, x, new_x)
-            f = fsa(x, new_x, f, idx)
+        for lvl, (fsa, (npoint, nsample)) in enumerate(zip(self.sa, self.sa_cfg)):
+            br.wait(ready[lvl])
+            new_x = samples[lvl]
+            idx = br.hold(knn(nsample, x, new_x))
+            f = br.hold(fsa(x, new_x, f, idx))
             x = new_x
             lv.append((x, f))
         (x11, f11), (x12, f12), (x13, f13), (x14, f14) = [(a[:B], b[:B]) for a, b in lv]
@@ -370,9 +430,9 @@ class FusedPWCLONet:
         pose = torch.empty((B, 4, 7), dtype=torch.float32, device=x.device)   # rows = levels 1..4
         q4, t4 = self.l4_head(emb4, mask4, pose, 3)
 
-        q3, t3, emb3, mask3 = self._refine(self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4)
-        q2, t2, emb2, mask2 = self._refine(self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3)
-        q1, t1, emb1, mask1 = self._refine(self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2)
+        q3, t3, emb3, mask3 = self._refine(br, self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4)
+        q2, t2, emb2, mask2 = self._refine(br, self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3)
+        q1, t1, emb1, mask1 = self._refine(br, self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2)
         if return_intermediates:
             return pose, dict(x11=x11, f11=f11, f13=f13, flow=flow, emb4=emb4, mask4=mask4, emb3=emb3,
                               mask3=mask3, emb1=emb1, mask1=mask1, q=(q1, q2, q3, q4), t=(t1, t2, t3, t4))

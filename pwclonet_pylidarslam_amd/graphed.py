@@ -13,10 +13,11 @@ class GraphedForward:
     mode.  Inputs (B,3,N) fp32 on the net's device; a new graph is captured per input shape.
     The returned tensor is a static buffer that the next call overwrites -- clone to keep it."""
 
-    def __init__(self, net, warmup=2):
+    def __init__(self, net, warmup=2, branch=True):
         assert not net.training, "graph capture is for eval mode (fixed control flow, no dropout)"
         self.net = net
         self.warmup = warmup
+        self.branch = branch      # fork/join the fused forward's independent branches inside the graph
         self._graphs = {}
         self._saved_log_mode = None
 
@@ -34,9 +35,17 @@ class GraphedForward:
                     net(s1, None, s2, None)
             torch.cuda.current_stream(s1.device).wait_stream(side)
             torch.cuda.synchronize(s1.device)
+            fused = getattr(net, "_fused", None)
+            saved_branch = fused.branch if fused is not None else None
+            if fused is not None:
+                fused.branch = fused.branch and self.branch
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph), torch.no_grad():
-                pose, log = net(s1, None, s2, None)
+            try:
+                with torch.cuda.graph(graph), torch.no_grad():
+                    pose, log = net(s1, None, s2, None)
+            finally:
+                if fused is not None:
+                    fused.branch = saved_branch
         finally:
             net.log_mode = log_mode
         return graph, s1, s2, pose, log
@@ -63,7 +72,9 @@ class PipelinedForward:
     that slot's stream has been synchronised (``wait(slot)`` / ``wait_all()``)."""
 
     def __init__(self, net, depth=2):
-        self.slots = [GraphedForward(net) for _ in range(depth)]
+        # single-branch graphs: two multi-branch graphs in flight serialise on this runtime
+        # (measured: 5.35 ms/step with branches vs 4.0 ms without, 2 in flight)
+        self.slots = [GraphedForward(net, branch=False) for _ in range(depth)]
         self.streams = None
         self.events = [None] * depth
         self._next = 0
