@@ -203,6 +203,34 @@ void pose_head_fused_kernel_wrapper(int b, int n, const float *emb, const float 
                                     const float *q_prev, const float *t_prev, float *q_out,
                                     float *t_out, float *pose_row, int row_stride);
 
+/* ---- 4. hoisted variants of section 3 ----------------------------------------------------------
+ * The first layer of every grouped MLP is linear in [geometry | feat_centre[s] | feat_nbr[n]]; the
+ * feature parts depend on one point only, so W_feat . feat[point] (+ bias) is computed once per
+ * point by linear_jobs and gathered by the pixel kernels as accumulator seeds (csrc/mlp_core.hpp,
+ * "Hoisting").  Same results as section 3 up to fp32 summation order. */
+
+/* Up to 6 independent per-point linear maps in one launch: out_j (npts_j, cout_j) = src_j (npts_j,
+ * cin_j) . W_j^T + bias_j, no activation; cin in {16,32,64}, cout in {16,32,64,128}; all seven
+ * arrays are HOST arrays of length njobs (pointers inside are device pointers). */
+void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int *cin, const int *cout,
+                                const float *const *src, const float *const *w, float *const *out);
+
+/* sa_fused with pre (b,n,c1) = W1_feat . feat + b1 (NULL at level 0, where layer 1 is whole). */
+void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, int c2, int c3, const float *xyz,
+                               const float *new_xyz, const float *pre, const int *idx,
+                               const float *packed_w, float *out);
+/* upconv_fused with pre (b,n,128) = W1_feat . feat1 + b1. */
+void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz2, const float *xyz1,
+                                   const float *pre, const int *idx, const float *packed_w, float *out);
+/* cv_fused_a1 with u (b,s,128) = W1_p . feat1 + b1 and v (b,n,128) = W1_q . feat2. */
+void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz1, const float *u,
+                                  const float *xyz2, const float *v, const int *idx,
+                                  const float *packed_w, float *pix);
+/* cv_fused_b with u2 (b,s,128) = W_p . feat1 + b, v2 (b,s,128) = W_f . first, first (b,s,64). */
+void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xyz1, const float *u2,
+                                 const float *v2, const float *first, const int *idx,
+                                 const float *packed_w, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,438 @@
+// Hoisted variants of the fused layers (gfx950): the per-point parts of every first layer are
+// precomputed once per point by linear_jobs_kernel; the pixel kernels gather those partial
+// products as accumulator seeds and run only the 16-channel geometry block of layer 1 (plus the
+// deeper layers) on the matrix cores.  See mlp_core.hpp "Hoisting".
+//
+//   set abstraction   [diff | feat[n]]              -> pre[n] = W1_feat feat[n] + b1
+//   set-upconv        [feat1[n] | diff]             -> pre[n] = W1_feat feat1[n] + b1
+//   cost volume a1    [geo | feat1[s] | feat2[n]]   -> u[s] = W1_p feat1[s] + b1, v[n] = W1_q feat2[n]
+//   cost volume b     [enc2 | feat1[s] | first[n]]  -> u2[s] = W_p feat1[s] + b,  v2[n] = W_f first[n]
+// MACs per pixel: set-upconv 18 432 -> 10 240, cv_a1 (C=64) 30 208 -> 14 592, cv_b (C=64) 33 408 -> 17 024.
+#include <math.h>
+#include <stdlib.h>
+
+#include "mlp_core.hpp"
+
+namespace pwclo {
+
+static int fh_tuning(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// 16-channel geometry block [p(3), q(3), q-p(3), |q-p|, 0 x 6] (costvolume.py:92-105), lane group g.
+__device__ __forceinline__ f32x4 geometry_block_h(const float *p, const float *q, int g) {
+  const float px = p[0], py = p[1], pz = p[2], qx = q[0], qy = q[1], qz = q[2];
+  const float dx = qx - px, dy = qy - py, dz = qz - pz;
+  const float euc = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-20f);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (g == 0) v = f32x4{px, py, pz, qx};
+  if (g == 1) v = f32x4{qy, qz, dx, dy};
+  if (g == 2) v = f32x4{dz, euc, 0.f, 0.f};
+  return v;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+#define PWCLO_H_TILE_LOOP(KP_, P_, S_, B_)                                                          \
+  constexpr int TILE = 16 * (P_);                                                                   \
+  const int pix_per_cloud = (S_) * (KP_);                                                           \
+  const int tiles_per_cloud = (pix_per_cloud + TILE - 1) / TILE;                                    \
+  const int ntiles = (B_) * tiles_per_cloud;                                                        \
+  for (int t = blockIdx.x * W + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * W)
+
+// ---- per-point linear maps (the hoisted partial products) -----------------------------------------
+struct LinJob {
+  const float *src;   // (npts, 16*nbi) point-major
+  const float *w;     // packed single layer (bias included, no activation)
+  float *out;         // (npts, 16*nbo)
+  int npts, nbi, nbo;
+};
+struct LinArgs { LinJob job[6]; };
+constexpr int LIN_WAVES = 8;
+
+template <int NBI, int NBO>
+__device__ __forceinline__ void linear_tiles(const LinJob &jb, const float *lds_w, int lane) {
+  constexpr int P = 2;
+  const int g = lane >> 4, j = lane & 15;
+  const int ntiles = (jb.npts + 16 * P - 1) / (16 * P);
+  for (int t = blockIdx.x * LIN_WAVES + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * LIN_WAVES) {
+    f32x4 in[NBI][P];
+    int pt[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int q = t * 16 * P + 16 * p + j;
+      pt[p] = q < jb.npts ? q : -1;
+      const float *row = jb.src + (size_t)(q < jb.npts ? q : jb.npts - 1) * (16 * NBI);
+#pragma unroll
+      for (int m = 0; m < NBI; ++m) in[m][p] = ld4(row + 16 * m + 4 * g);
+    }
+    f32x4 o1[NBO][P];
+    mlp_layer<NBI, NBO, P, false>(o1, in, lds_w, lane);
+#pragma unroll
+    for (int o = 0; o < NBO; ++o)
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (pt[p] >= 0)
+          *reinterpret_cast<f32x4 *>(jb.out + (size_t)pt[p] * (16 * NBO) + 16 * o + 4 * g) = o1[o][p];
+  }
+}
+
+__global__ __launch_bounds__(LIN_WAVES * 64) void linear_jobs_kernel(LinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  const LinJob jb = a.job[blockIdx.y];
+  stage_weights(lds_w, jb.w, layer_floats(jb.nbi, jb.nbo));
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+#define LJ(I, O) if (jb.nbi == I && jb.nbo == O) { linear_tiles<I, O>(jb, lds_w, lane); return; }
+  LJ(1, 1) LJ(1, 2) LJ(1, 4) LJ(1, 8) LJ(2, 1) LJ(2, 2) LJ(2, 4) LJ(2, 8) LJ(4, 1) LJ(4, 2) LJ(4, 4) LJ(4, 8)
+#undef LJ
+}
+
+// ---- set abstraction, hoisted ------------------------------------------------------------------------
+struct SAHArgs {
+  const float *xyz, *new_xyz;   // (B,N,3), (B,S,3)
+  const float *pre;             // (B,N,16*B1) = W1_feat feat + b1, or nullptr (level 0: plain bias)
+  const int *idx;               // (B,S,K)
+  const float *w;               // packed: layer 1 on the geometry block, layers 2, 3
+  float *out;                   // (B,S,16*B3)
+  int B, N, S, K;
+};
+
+template <int B1, int B2, int B3, int KP, int P, int W, bool XYZ_ONLY>
+__global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
+  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats(B1, B2), W3 = layer_floats(B2, B3);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, W1 + W2 + W3);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  constexpr int C1 = 16 * B1, C3 = 16 * B3;
+  PWCLO_H_TILE_LOOP(KP, P, a.S, a.B) {
+    const int b = t / tiles_per_cloud;
+    const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    f32x4 in[1][P];
+    int sq[P];
+    const float *prow[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const PixelMap<KP> pm(pix0 + 16 * p + j);
+      const bool valid = pm.s < a.S;
+      const int s = valid ? pm.s : a.S - 1;
+      const int k = pm.k < a.K ? pm.k : 0;
+      sq[p] = valid ? s : -1;
+      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
+      const float *c = a.new_xyz + ((size_t)b * a.S + s) * 3;
+      const float *q = a.xyz + ((size_t)b * a.N + nbr) * 3;
+      const float qx = q[0], qy = q[1], qz = q[2];
+      f32x4 geo = {0.f, 0.f, 0.f, 0.f};
+      if (g == 0) geo = f32x4{qx - c[0], qy - c[1], qz - c[2], XYZ_ONLY ? qx : 0.f};
+      if (XYZ_ONLY && g == 1) geo = f32x4{qy, qz, 0.f, 0.f};
+      in[0][p] = geo;
+      prow[p] = XYZ_ONLY ? nullptr : a.pre + ((size_t)b * a.N + nbr) * C1 + 4 * g;
+    }
+    f32x4 h1[B1][P], h2[B2][P], h3[B3][P];
+    if (XYZ_ONLY) {
+      mlp_layer<1, B1, P, true>(h1, in, lds_w, lane);
+    } else {
+      mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane, [&](int o, int p) { return ld4(prow[p] + 16 * o); });
+    }
+    mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    mlp_layer<B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
+    constexpr int GROUP = KP < 16 ? KP : 16;
+    constexpr int BPQ = KP > 16 ? KP / 16 : 1;
+#pragma unroll
+    for (int o = 0; o < B3; ++o) {
+#pragma unroll
+      for (int p = 0; p < P; p += BPQ) {
+        f32x4 v = h3[o][p];
+#pragma unroll
+        for (int e = 1; e < BPQ; ++e) {
+          const f32x4 u = h3[o][p + e];
+          v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
+        }
+        v.x = group_max_nonneg<GROUP>(v.x); v.y = group_max_nonneg<GROUP>(v.y);
+        v.z = group_max_nonneg<GROUP>(v.z); v.w = group_max_nonneg<GROUP>(v.w);
+        if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
+          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * C3 + 16 * o + 4 * g) = v;
+      }
+    }
+  }
+}
+
+// ---- set-upconv, hoisted --------------------------------------------------------------------------------
+struct UpHArgs {
+  const float *xyz2, *xyz1;   // (B,S,3) fine queries, (B,N,3) coarse points
+  const float *pre;           // (B,N,128) = W1_feat feat1 + b1
+  const int *idx;             // (B,S,K)
+  const float *w;             // packed: layer 1 on the diff block (-> 128), layer 2 (128 -> 64)
+  float *out;                 // (B,S,64)
+  int B, N, S, K;
+};
+
+template <int KP, int P, int W>
+__global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
+  constexpr int B1 = 8, B2 = 4;
+  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats(B1, B2);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, W1 + W2);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  PWCLO_H_TILE_LOOP(KP, P, a.S, a.B) {
+    const int b = t / tiles_per_cloud;
+    const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    f32x4 in[1][P];
+    int sq[P];
+    const float *prow[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const PixelMap<KP> pm(pix0 + 16 * p + j);
+      const bool valid = pm.s < a.S;
+      const int s = valid ? pm.s : a.S - 1;
+      const int k = pm.k < a.K ? pm.k : 0;
+      sq[p] = valid ? s : -1;
+      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
+      const float *c = a.xyz2 + ((size_t)b * a.S + s) * 3;
+      const float *q = a.xyz1 + ((size_t)b * a.N + nbr) * 3;
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+      if (g == 0) d = f32x4{q[0] - c[0], q[1] - c[1], q[2] - c[2], 0.f};
+      in[0][p] = d;
+      prow[p] = a.pre + ((size_t)b * a.N + nbr) * 128 + 4 * g;
+    }
+    f32x4 h1[B1][P], h2[B2][P];
+    mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane, [&](int o, int p) { return ld4(prow[p] + 16 * o); });
+    mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    constexpr int GROUP = KP < 16 ? KP : 16;
+#pragma unroll
+    for (int o = 0; o < B2; ++o)
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        f32x4 v = h2[o][p];
+        v.x = group_max_nonneg<GROUP>(v.x); v.y = group_max_nonneg<GROUP>(v.y);
+        v.z = group_max_nonneg<GROUP>(v.z); v.w = group_max_nonneg<GROUP>(v.w);
+        if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
+          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = v;
+      }
+  }
+}
+
+// ---- cost volume a1 / b, hoisted ------------------------------------------------------------------------
+struct CVHArgs {
+  const float *xyz1;    // (B,S,3) queries
+  const float *u;       // (B,S,128) centre partial product (bias included)
+  const float *xyz2;    // (B,N,3) candidates
+  const float *v;       // (B,N,128) neighbour partial product
+  const float *val;     // b only: (B,N,64) first-aggregate result (the softmax-weighted values)
+  const int *idx;       // (B,S,K)
+  const float *w;       // packed weights
+  float *out;           // a1: pix (B,S*KP,64); b: (B,S,64)
+  int B, N, S, K;
+};
+
+template <int KP, int P, int W>
+__global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
+  constexpr int B1 = 8, B2 = 4, B3 = 4;
+  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats(B1, B2), W3 = layer_floats(B2, B3);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, W1 + W2 + W3);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  PWCLO_H_TILE_LOOP(KP, P, a.S, a.B) {
+    const int b = t / tiles_per_cloud;
+    const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    f32x4 in[1][P];
+    int pixv[P];
+    const float *urow[P], *vrow[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int pix = pix0 + 16 * p + j;
+      const PixelMap<KP> pm(pix);
+      const bool valid = pm.s < a.S;
+      const int s = valid ? pm.s : a.S - 1;
+      const int k = pm.k < a.K ? pm.k : 0;
+      pixv[p] = valid ? pix : -1;
+      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
+      in[0][p] = geometry_block_h(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
+      urow[p] = a.u + ((size_t)b * a.S + s) * 128 + 4 * g;
+      vrow[p] = a.v + ((size_t)b * a.N + nbr) * 128 + 4 * g;
+    }
+    f32x4 h1[B1][P], h2[B2][P], h3[B3][P];
+    mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane,
+                                   [&](int o, int p) { return ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o); });
+    mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    mlp_layer<B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
+#pragma unroll
+    for (int o = 0; o < B3; ++o)
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (pixv[p] >= 0)
+          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * pix_per_cloud + pixv[p]) * 64 + 16 * o + 4 * g) = h3[o][p];
+  }
+}
+
+template <int KP, int P, int W>
+__global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats(4, 8), W2 = layer_floats(8, 4);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, WX + W1 + W2);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  PWCLO_H_TILE_LOOP(KP, P, a.S, a.B) {
+    const int b = t / tiles_per_cloud;
+    const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    f32x4 geo[1][P], val[4][P];
+    int sq[P];
+    bool padded[P];
+    const float *urow[P], *vrow[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const PixelMap<KP> pm(pix0 + 16 * p + j);
+      const bool valid = pm.s < a.S;
+      const int s = valid ? pm.s : a.S - 1;
+      padded[p] = pm.k >= a.K;
+      const int k = padded[p] ? 0 : pm.k;
+      sq[p] = valid ? s : -1;
+      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
+      geo[0][p] = geometry_block_h(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
+      urow[p] = a.u + ((size_t)b * a.S + s) * 128 + 4 * g;
+      vrow[p] = a.v + ((size_t)b * a.N + nbr) * 128 + 4 * g;
+      const float *fr = a.val + ((size_t)b * a.N + nbr) * 64 + 4 * g;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) val[m][p] = ld4(fr + 16 * m);
+    }
+    f32x4 enc[4][P], h1[8][P], h2[4][P];
+    mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
+    mlp_layer_init<4, 8, P, true>(h1, enc, lds_w + WX, lane,
+                                  [&](int o, int p) { return ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o); });
+    mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+    // softmax over the neighbours, weighted sum of the gathered first-aggregate rows
+    constexpr int GROUP = KP < 16 ? KP : 16;
+    const float NEG_INF = __int_as_float(0xff800000);
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        f32x4 res;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float xv = padded[p] ? NEG_INF : h2[o][p][c];
+          const float mx = group_max_nonneg<GROUP>(xv);
+          const float ex = padded[p] ? 0.f : expf(xv - mx);
+          const float den = group_sum<GROUP>(ex);
+          const float num = group_sum<GROUP>(ex * val[o][p][c]);
+          res[c] = num / den;
+        }
+        if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
+          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = res;
+      }
+  }
+}
+
+// ---- launch helpers ----------------------------------------------------------------------------------------
+template <int W, typename Kern, typename Args>
+static void launch_h(Kern kern, bool &attr_set, int lds_bytes, long long ntiles, const Args &a) {
+  if (lds_bytes > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
+  static const int rounds = fh_tuning("PWCLO_FL_ROUNDS", 2);
+  const int per_cu = (lds_bytes > 80 * 1024 || W > 8) ? 1 : 2;
+  long long grid = (ntiles + W - 1) / W;
+  if (grid > 256LL * per_cu * rounds) grid = 256LL * per_cu * rounds;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W * 64), lds_bytes, current_stream(), a);
+}
+
+static long long tiles_h(int b, int s, int kp, int p) {
+  return (long long)b * (((long long)s * kp + 16 * p - 1) / (16 * p));
+}
+
+}  // namespace pwclo
+
+using namespace pwclo;
+
+extern "C" void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int *cin, const int *cout,
+                                           const float *const *src, const float *const *w,
+                                           float *const *out) {
+  if (njobs <= 0) return;
+  PWCLO_REQUIRE(njobs <= 6, "linear_jobs: at most 6 jobs per launch (got %d)", njobs);
+  LinArgs a;
+  int max_tiles = 1, max_lds = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const bool ok = (cin[i] == 16 || cin[i] == 32 || cin[i] == 64) &&
+                    (cout[i] == 16 || cout[i] == 32 || cout[i] == 64 || cout[i] == 128);
+    PWCLO_REQUIRE(ok, "linear_jobs: job %d has unsupported channels %d -> %d", i, cin[i], cout[i]);
+    a.job[i] = LinJob{src[i], w[i], out[i], npts[i], cin[i] / 16, cout[i] / 16};
+    max_tiles = max(max_tiles, ceil_div(npts[i], 32));
+    max_lds = max(max_lds, 4 * layer_floats(cin[i] / 16, cout[i] / 16));
+  }
+  int gx = ceil_div(max_tiles, LIN_WAVES);
+  const int cap = max(1, 512 / njobs);
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(linear_jobs_kernel, dim3(gx, njobs), dim3(LIN_WAVES * 64), max_lds, current_stream(), a);
+  check_launch("linear_jobs");
+}
+
+extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, int c2, int c3, const float *xyz,
+                                          const float *new_xyz, const float *pre, const int *idx,
+                                          const float *packed_w, float *out) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k >= 1 && k <= 32, "sa_fused_h: nsample=%d outside [1,32]", k);
+  SAHArgs a{xyz, new_xyz, pre, idx, packed_w, out, b, n, s, k};
+  const int kp = k > 16 ? 32 : 16;
+  const bool lvl0 = pre == nullptr;
+#define SAH_CASE(A1, A2, A3, KP, XYZ, PP, WW)                                                         \
+  if (c1 == A1 && c2 == A2 && c3 == A3 && kp == KP && lvl0 == XYZ) {                                  \
+    static bool attr = false;                                                                         \
+    constexpr int lds = 4 * (layer_floats(1, A1 / 16) + layer_floats(A1 / 16, A2 / 16) +               \
+                             layer_floats(A2 / 16, A3 / 16));                                          \
+    launch_h<WW>(sa_h_kernel<A1 / 16, A2 / 16, A3 / 16, KP, PP, WW, XYZ>, attr, lds, tiles_h(b, s, KP, PP), a); \
+    check_launch("sa_fused_h");                                                                       \
+    return;                                                                                           \
+  }
+  SAH_CASE(16, 16, 16, 32, true, 2, 8)      // psa_1
+  SAH_CASE(16, 16, 32, 32, false, 2, 8)     // psa_2
+  SAH_CASE(32, 32, 64, 16, false, 1, 16)    // psa_3
+  SAH_CASE(64, 64, 128, 16, false, 1, 16)   // psa_4
+  SAH_CASE(128, 64, 64, 16, false, 1, 16)   // flow_feature_encoding
+#undef SAH_CASE
+  set_error(PWCLO_EINVAL, "sa_fused_h: no kernel for mlp=(%d,%d,%d) nsample=%d level0=%d", c1, c2, c3, k, (int)lvl0);
+}
+
+extern "C" void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz2, const float *xyz1,
+                                              const float *pre, const int *idx, const float *packed_w,
+                                              float *out) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k >= 1 && k <= 8, "upconv_fused_h: nsample=%d outside [1,8]", k);
+  UpHArgs a{xyz2, xyz1, pre, idx, packed_w, out, b, n, s, k};
+  static bool attr = false;
+  constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4));
+  launch_h<16>(upconv_h_kernel<8, 1, 16>, attr, lds, tiles_h(b, s, 8, 1), a);
+  check_launch("upconv_fused_h");
+}
+
+extern "C" void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz1, const float *u,
+                                             const float *xyz2, const float *v, const int *idx,
+                                             const float *packed_w, float *pix) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a1_h: nsample_q=%d outside [1,32]", k);
+  CVHArgs a{xyz1, u, xyz2, v, nullptr, idx, packed_w, pix, b, n, s, k};
+  const int kp = k > 16 ? 32 : (k > 8 ? 16 : 8);
+  constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4) + layer_floats(4, 4));
+  static bool a32 = false, a16 = false, a8 = false;
+  if (kp == 32) launch_h<8>(cv_a1_h_kernel<32, 2, 8>, a32, lds, tiles_h(b, s, 32, 2), a);
+  else if (kp == 16) launch_h<16>(cv_a1_h_kernel<16, 1, 16>, a16, lds, tiles_h(b, s, 16, 1), a);
+  else launch_h<16>(cv_a1_h_kernel<8, 1, 16>, a8, lds, tiles_h(b, s, 8, 1), a);
+  check_launch("cv_fused_a1_h");
+}
+
+extern "C" void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xyz1, const float *u2,
+                                            const float *v2, const float *first, const int *idx,
+                                            const float *packed_w, float *out) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k >= 1 && k <= 4, "cv_fused_b_h: nsample=%d outside [1,4]", k);
+  CVHArgs a{xyz1, u2, xyz1, v2, first, idx, packed_w, out, b, s, s, k};
+  static bool attr = false;
+  constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(4, 8) + layer_floats(8, 4));
+  launch_h<16>(cv_b_h_kernel<4, 1, 16>, attr, lds, tiles_h(b, s, 4, 1), a);
+  check_launch("cv_fused_b_h");
+}

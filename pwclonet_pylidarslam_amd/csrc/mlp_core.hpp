@@ -40,11 +40,11 @@ __device__ __forceinline__ void stage_weights(float *lds, const float *__restric
 // tile's ds_read_b128 issued before the current tile's 4*P MFMAs (register double buffer, 8 VGPRs),
 // so the LDS latency sits under matrix work; a sched_barrier per tile keeps the scheduler from
 // hoisting every later read as well (which spilled).
-template <int NBI, int NBO, int P, bool RELU>
-__device__ __forceinline__ void mlp_layer(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
-                                          const float *w, int lane) {
-  const int g = lane >> 4;
-  const float *bias = w + NBO * NBI * 256;
+// `init(o, p)` seeds the accumulator of output block o / pixel block p: the layer's bias, or --
+// for hoisted first layers -- the per-point partial products gathered from memory (see below).
+template <int NBI, int NBO, int P, bool RELU, typename Init>
+__device__ __forceinline__ void mlp_layer_init(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
+                                               const float *w, int lane, Init init) {
   const float *wl = w + lane * 4;
   f32x4 wv = *reinterpret_cast<const f32x4 *>(wl);
   f32x4 acc[P];
@@ -54,9 +54,8 @@ __device__ __forceinline__ void mlp_layer(f32x4 (&out)[NBO][P], const f32x4 (&in
     f32x4 wnext = wv;
     if (t + 1 < NBO * NBI) wnext = *reinterpret_cast<const f32x4 *>(wl + (t + 1) * 256);
     if (m == 0) {
-      const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 16 * o + 4 * g);
 #pragma unroll
-      for (int p = 0; p < P; ++p) acc[p] = bv;
+      for (int p = 0; p < P; ++p) acc[p] = init(o, p);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -80,6 +79,22 @@ __device__ __forceinline__ void mlp_layer(f32x4 (&out)[NBO][P], const f32x4 (&in
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+template <int NBI, int NBO, int P, bool RELU>
+__device__ __forceinline__ void mlp_layer(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
+                                          const float *w, int lane) {
+  const float *bias = w + NBO * NBI * 256 + 4 * (lane >> 4);
+  mlp_layer_init<NBI, NBO, P, RELU>(out, in, w, lane, [&](int o, int) {
+    return *reinterpret_cast<const f32x4 *>(bias + 16 * o);
+  });
+}
+
+// Hoisting.  The first layer of a grouped MLP is linear in its concatenated input
+// [geometry(q,p) | feat_centre[s] | feat_nbr[n]], and the feature parts depend on ONE point, not on
+// the (query, neighbour) pixel.  W_feat . feat[point] (+ bias) is therefore computed once per
+// point by linear_jobs_kernel (K x fewer MACs than per pixel) and the pixel kernels seed their
+// first-layer accumulators with the gathered rows, leaving only the 16-channel geometry block
+// for the per-pixel MFMAs.  Same mathematics, different fp32 summation order (parity bound 1e-5).
 
 // ---- start-up stagger ------------------------------------------------------------------------------
 // All waves of a workgroup start their first tile together, and because they share one matrix pipe

@@ -300,6 +300,198 @@ class FusedPoseHead:
         return q, t
 
 
+# ---- hoisted first layers (csrc/fused_hoisted.hip) ------------------------------------------------------
+
+class LinearJob:
+    """out = src . W^T + bias over points (no activation): one hoisted partial product."""
+
+    def __init__(self, w, b):
+        self.cout, self.cin = w.shape
+        assert self.cin in (16, 32, 64) and self.cout in (16, 32, 64, 128)
+        self.packed = pack_layer(w, b, list(range(self.cin)))
+
+
+def run_linear_jobs(jobs):
+    """jobs: list of (LinearJob, src (B,N,cin) contiguous) -> list of (B,N,cout) tensors, one launch
+    per <= 6 jobs."""
+    import ctypes
+    outs = []
+    for start in range(0, len(jobs), 6):
+        chunk = jobs[start:start + 6]
+        n = len(chunk)
+        srcs = [s_ for _, s_ in chunk]
+        res = [torch.empty(s_.shape[:-1] + (j.cout,), dtype=torch.float32, device=s_.device) for j, s_ in chunk]
+        npts = [s_.shape[0] * s_.shape[1] for s_ in srcs]
+        ia = lambda v: (ctypes.c_int * n)(*v)
+        pa = lambda v: (ctypes.c_void_p * n)(*v)
+        _lib.annotate(family="mlp", flops=2.0 * sum(p_ * j.cin * j.cout for p_, (j, _) in zip(npts, chunk)),
+                      bytes=4.0 * sum(p_ * (j.cin + j.cout) for p_, (j, _) in zip(npts, chunk)))
+        _lib.call("linear_jobs_kernel_wrapper", srcs[0].device, n, ia(npts), ia([j.cin for j, _ in chunk]),
+                  ia([j.cout for j, _ in chunk]), pa([_p(s_) for s_ in srcs]),
+                  pa([_p(j.packed) for j, _ in chunk]), pa([_p(r) for r in res]))
+        outs.extend(res)
+    return outs
+
+
+def _zeros_like_bias(w):
+    return torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
+
+
+def _pack_rest(layers, cout_prev):
+    """Pack layers 2.. of a stack fed by a previous layer with `cout_prev` real outputs."""
+    parts, widths = [], []
+    for layer in layers:
+        w, b = fold_conv_bn(layer)
+        nbo = (w.shape[0] + 15) // 16
+        parts.append(pack_layer(w, b, chain_map(cout_prev, (cout_prev + 15) // 16), nbo))
+        widths.append(16 * nbo)
+        cout_prev = w.shape[0]
+    return parts, widths
+
+
+class FusedSAHoisted:
+    """``PointnetSAModulePWCLONet`` with the feature part of layer 1 hoisted to a per-point map."""
+
+    def __init__(self, module):
+        layers = list(module.mlp_module)
+        w1, b1 = fold_conv_bn(layers[0])
+        cin = w1.shape[1]
+        self.c_feat = cin - 3 if cin != 6 else 0
+        nbo1 = (w1.shape[0] + 15) // 16
+        if self.c_feat:
+            # original order [xyz_diff(3), feat(C)] (pointnet2_modules.py:222)
+            self.pre_job = LinearJob(_pad_rows(w1[:, 3:], 16 * nbo1), _pad_rows(b1, 16 * nbo1))
+            first = pack_layer(w1[:, :3], _zeros_like_bias(w1), [0, 1, 2] + [-1] * 13, nbo1)
+        else:
+            self.pre_job = None
+            first = pack_layer(w1, b1, [0, 1, 2, 3, 4, 5] + [-1] * 10, nbo1)
+        rest, widths = _pack_rest(layers[1:], w1.shape[0])
+        self.packed = torch.cat([first] + rest).contiguous()
+        self.widths = [16 * nbo1] + widths
+        self.c_out = layers[-1].conv.weight.shape[0]
+        self.macs = stack_macs(module.mlp_module) - self.c_feat * w1.shape[0]   # per pixel, after hoisting
+        self.nsample = module.nsample
+
+    def jobs(self, feat_pm):
+        return [(self.pre_job, feat_pm)] if self.pre_job is not None else []
+
+    def __call__(self, xyz, new_xyz, pre, idx):
+        B, N, _ = xyz.shape
+        S, K = idx.shape[1], idx.shape[2]
+        out = torch.empty((B, S, self.c_out), dtype=torch.float32, device=xyz.device)
+        _lib.annotate(family="mlp", flops=2.0 * B * S * K * self.macs,
+                      bytes=4.0 * B * (S * K * (1 + 3 + self.widths[0]) + 3 * S + S * self.c_out))
+        _lib.call("sa_fused_h_kernel_wrapper", xyz.device, B, N, S, K, *self.widths, _p(xyz), _p(new_xyz),
+                  _p(pre), _p(idx), _p(self.packed), _p(out))
+        return out
+
+
+def _pad_rows(t, rows):
+    """Zero-pad a (cout, ...) weight / (cout,) bias to `rows` output channels."""
+    if t.shape[0] == rows:
+        return t
+    pad = torch.zeros((rows - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    return torch.cat((t, pad), dim=0)
+
+
+class FusedUpconvHoisted:
+    """``PointnetFPModulePWCLONet`` (knn branch): layer 1 = W_feat.feat1[n] (hoisted) + W_diff.diff."""
+
+    def __init__(self, module):
+        assert module.knn and module.use_xyz
+        layers = list(module.mlp)
+        w1, b1 = fold_conv_bn(layers[0])
+        assert w1.shape == (128, 67), "set-upconv kernel is built for 64-channel coarse features"
+        self.pre_job = LinearJob(w1[:, :64], b1)                     # original order [feat(64), diff(3)], :490
+        first = pack_layer(w1[:, 64:67], _zeros_like_bias(w1), [0, 1, 2] + [-1] * 13, 8)
+        rest, widths = _pack_rest(layers[1:], 128)
+        assert widths == [64]
+        self.packed = torch.cat([first] + rest).contiguous()
+        c2 = list(module.post_mlp)[0].conv.weight.shape[1] - 64
+        self.post = FusedPointwise(module.post_mlp, [64, c2])
+        self.macs = stack_macs(module.mlp)
+
+    def jobs(self, feat1):
+        return [(self.pre_job, feat1)]
+
+    def __call__(self, xyz2, xyz1, feat2, pre, idx):
+        B, S, _ = xyz2.shape
+        N, K = xyz1.shape[1], idx.shape[2]
+        pooled = torch.empty((B, S, 64), dtype=torch.float32, device=xyz2.device)
+        _lib.annotate(family="mlp", flops=2.0 * B * S * K * (self.macs - 64 * 128),
+                      bytes=4.0 * B * (S * K * (1 + 3 + 128) + 3 * S + 64 * S))
+        _lib.call("upconv_fused_h_kernel_wrapper", xyz2.device, B, N, S, K, _p(xyz2), _p(xyz1), _p(pre),
+                  _p(idx), _p(self.packed), _p(pooled))
+        return self.post(pooled, feat2)
+
+
+class FusedCostVolumeHoisted:
+    """``CostVolume``: centre / neighbour feature parts of mlp_convs[0] and mlp3_convs[0] hoisted."""
+
+    def __init__(self, module):
+        c1, c2, _ = module.in_channel
+        assert c1 == c2 and c1 in (16, 32, 64)
+        self.c = c = c1
+        self.nsample, self.nsample_q = module.nsample, module.nsample_q
+        geo = list(range(10)) + [-1] * 6
+        la = list(module.mlp_convs)
+        w1, b1 = fold_conv_bn(la[0])                                   # [geo(10) | feat1 (C) | feat2 (C)]
+        self.job_u = LinearJob(w1[:, 10:10 + c], b1)
+        self.job_v = LinearJob(w1[:, 10 + c:10 + 2 * c], _zeros_like_bias(w1))
+        first = pack_layer(w1[:, :10], _zeros_like_bias(w1), geo, 8)
+        rest, widths = _pack_rest(la[1:], 128)
+        assert widths == [64, 64]
+        self.w_a1 = torch.cat([first] + rest).contiguous()
+        wx1, wd = pack_stack(module.mlp_conv_xyz_1, geo)
+        w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)))
+        assert wd == [64] and wd2 == [128, 64]
+        self.w_a2 = torch.cat((wx1, w2)).contiguous()
+        wx2, _ = pack_stack(module.mlp_conv_xyz_2, geo)
+        lb = list(module.mlp3_convs)
+        w3, b3 = fold_conv_bn(lb[0])                                   # [enc2 (64) | feat1 (C) | first (64)]
+        self.job_u2 = LinearJob(w3[:, 64:64 + c], b3)
+        self.job_v2 = LinearJob(w3[:, 64 + c:], _zeros_like_bias(w3))
+        first_b = pack_layer(w3[:, :64], _zeros_like_bias(w3), list(range(64)), 8)
+        rest_b, wdb = _pack_rest(lb[1:], 128)
+        assert wdb == [64]
+        self.w_b = torch.cat([wx2, first_b] + rest_b).contiguous()
+        self.macs_a1 = stack_macs(module.mlp_convs)
+        self.macs_a2 = stack_macs(module.mlp_conv_xyz_1) + stack_macs(module.mlp2_convs)
+        self.macs_b = stack_macs(module.mlp_conv_xyz_2) + stack_macs(module.mlp3_convs)
+
+    def jobs(self, feat1, feat2):
+        """The three partial products that only need the inputs: u, v (first aggregate), u2."""
+        return [(self.job_u, feat1), (self.job_v, feat2), (self.job_u2, feat1)]
+
+    def __call__(self, xyz1, xyz2, u, v, u2, idx_q=None, idx=None):
+        B, S, _ = xyz1.shape
+        N = xyz2.shape[1]
+        dev = xyz1.device
+        kq, k, c = self.nsample_q, self.nsample, self.c
+        if idx_q is None:
+            idx_q = knn(kq, xyz2, xyz1)
+        kp = 32 if kq > 16 else (16 if kq > 8 else 8)
+        pix = torch.empty((B, S * kp, 64), dtype=torch.float32, device=dev)
+        _lib.annotate(family="mlp", flops=2.0 * B * S * kq * (self.macs_a1 - 2 * c * 128),
+                      bytes=4.0 * B * (S * kq * (1 + 3 + 128 + 64) + S * (3 + 128)))
+        _lib.call("cv_fused_a1_h_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(u), _p(xyz2), _p(v), _p(idx_q),
+                  _p(self.w_a1), _p(pix))
+        first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
+        _lib.annotate(family="mlp", flops=2.0 * B * S * kq * self.macs_a2,
+                      bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
+        _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
+                  _p(self.w_a2), _p(pix), _p(first))
+        if idx is None:
+            idx = knn(k, xyz1, xyz1)
+        (v2,) = run_linear_jobs([(self.job_v2, first)])
+        out = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
+        _lib.annotate(family="mlp", flops=2.0 * B * S * k * (self.macs_b - (c + 64) * 128),
+                      bytes=4.0 * B * (S * k * (1 + 3 + 128 + 64) + S * (3 + 128 + 64)))
+        _lib.call("cv_fused_b_h_kernel_wrapper", dev, B, S, k, _p(xyz1), _p(u2), _p(v2), _p(first), _p(idx),
+                  _p(self.w_b), _p(out))
+        return out
+
+
 # ---- whole network --------------------------------------------------------------------------------------
 
 class _Branches:
@@ -359,11 +551,15 @@ class FusedPWCLONet:
         assert not net.training, "the fused path implements eval-mode semantics"
         import os
         self.branch = os.environ.get("PWCLO_BRANCH", "1") != "0"   # fork/join streams under graph capture
+        # hoisted first layers (per-point partial products, csrc/fused_hoisted.hip); 0 = section-3 kernels
+        self.hoist = os.environ.get("PWCLO_HOIST", "1") != "0"
+        SA, UP, CV = ((FusedSAHoisted, FusedUpconvHoisted, FusedCostVolumeHoisted) if self.hoist else
+                      (FusedSA, FusedUpconv, FusedCostVolume))
         self.pw = pw
-        self.sa = [FusedSA(m) for m in (net.psa_1, net.psa_2, net.psa_3, net.psa_4)]
+        self.sa = [SA(m) for m in (net.psa_1, net.psa_2, net.psa_3, net.psa_4)]
         self.sa_cfg = [(m.npoint, m.nsample) for m in (net.psa_1, net.psa_2, net.psa_3, net.psa_4)]
-        self.cv3 = FusedCostVolume(net.cost_volume)
-        self.ffe = FusedSA(net.flow_feature_encoding)
+        self.cv3 = CV(net.cost_volume)
+        self.ffe = SA(net.flow_feature_encoding)
         self.ffe_cfg = (net.flow_feature_encoding.npoint, net.flow_feature_encoding.nsample)
         self.l4_pred = FusedPointwise(net.l4_flow_predictor.mlp_convs, [128, 64])
         self.l4_head = FusedPoseHead(net.pose_calculator_4)
@@ -371,8 +567,7 @@ class FusedPWCLONet:
         for lvl, m in ((3, net.pose_warp_refinement_3), (2, net.pose_warp_refinement_2),
                        (1, net.pose_warp_refinement_1)):
             c = m.in_channel[0]
-            d = dict(up_f=FusedUpconv(m.setupconv_features), up_m=FusedUpconv(m.setupconv_mask),
-                     cv=FusedCostVolume(m.cost_volume),
+            d = dict(up_f=UP(m.setupconv_features), up_m=UP(m.setupconv_mask), cv=CV(m.cost_volume),
                      pred_f=FusedPointwise(m.flow_predictor_features.mlp_convs, [c, 64, 64]),
                      pred_m=None if m.last_pose_estimation else
                      FusedPointwise(m.flow_predictor_mask.mlp_convs, [64, 64, c]),
@@ -381,12 +576,15 @@ class FusedPWCLONet:
 
     def _refine(self, br, d, row, pose, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev):
         idx_up = br.hold(knn(8, x1_prev, x1))
+        if self.hoist:          # all per-point partial products of this level in one launch
+            pre_f, pre_m, u, v, u2 = br.hold(*run_linear_jobs(
+                d["up_f"].jobs(emb_prev) + d["up_m"].jobs(mask_prev) + d["cv"].jobs(f1, f2)))
         with br.fork(1):        # set-upconv of the features ...
-            up_feat = br.hold(d["up_f"](x1, x1_prev, f1, emb_prev, idx_up))
+            up_feat = br.hold(d["up_f"](x1, x1_prev, f1, pre_f if self.hoist else emb_prev, idx_up))
         with br.fork(2):        # ... and of the mask are independent of the warp -> cost-volume chain
-            up_mask = br.hold(d["up_m"](x1, x1_prev, f1, mask_prev, idx_up))
+            up_mask = br.hold(d["up_m"](x1, x1_prev, f1, pre_m if self.hoist else mask_prev, idx_up))
         warped = br.hold(quat_warp_pm(x1, q_prev, t_prev))
-        resid = br.hold(d["cv"](warped, f1, x2, f2))
+        resid = br.hold(d["cv"](warped, x2, u, v, u2) if self.hoist else d["cv"](warped, f1, x2, f2))
         br.join(1)
         br.join(2)
         emb = d["pred_f"](f1, resid, up_feat)
@@ -417,15 +615,23 @@ class FusedPWCLONet:
             br.wait(ready[lvl])
             new_x = samples[lvl]
             idx = br.hold(knn(nsample, x, new_x))
-            f = br.hold(fsa(x, new_x, f, idx))
+            if self.hoist:
+                pre = br.hold(run_linear_jobs(fsa.jobs(f))[0]) if f is not None else None
+                f = br.hold(fsa(x, new_x, pre, idx))
+            else:
+                f = br.hold(fsa(x, new_x, f, idx))
             x = new_x
             lv.append((x, f))
         (x11, f11), (x12, f12), (x13, f13), (x14, f14) = [(a[:B], b[:B]) for a, b in lv]
         (x21, f21), (x22, f22), (x23, f23), _ = [(a[B:], b[B:]) for a, b in lv]
 
-        flow = self.cv3(x13, f13, x23, f23)
         # flow_feature_encoding samples the same cloud as psa_4(frame 1): reuse x14
-        emb4 = self.ffe(x13, x14, flow, knn(self.ffe_cfg[1], x13, x14))
+        if self.hoist:
+            flow = self.cv3(x13, x23, *run_linear_jobs(self.cv3.jobs(f13, f23)))
+            emb4 = self.ffe(x13, x14, run_linear_jobs(self.ffe.jobs(flow))[0], knn(self.ffe_cfg[1], x13, x14))
+        else:
+            flow = self.cv3(x13, f13, x23, f23)
+            emb4 = self.ffe(x13, x14, flow, knn(self.ffe_cfg[1], x13, x14))
         mask4 = self.l4_pred(f14, emb4)
         pose = torch.empty((B, 4, 7), dtype=torch.float32, device=x.device)   # rows = levels 1..4
         q4, t4 = self.l4_head(emb4, mask4, pose, 3)

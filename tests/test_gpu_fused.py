@@ -43,15 +43,20 @@ def cloud(seed, b, n, scale=10.0):
     ("psa_3", [32, 32, 32, 64], 64, 16, 256, 32), ("psa_4", [64, 64, 64, 128], 16, 16, 64, 64),
     ("flow_feature_encoding", [64, 128, 64, 64], 64, 16, 256, 64),
     ("psa_3", [32, 32, 32, 64], 37, 11, 301, 32)])     # ragged: K < KP, S*KP not a tile multiple
-def test_fused_set_abstraction(cuda, name, mlp, npoint, nsample, n, c):
+@pytest.mark.parametrize("hoist", [False, True])
+def test_fused_set_abstraction(cuda, name, mlp, npoint, nsample, n, c, hoist):
     mod, osd = filled(PointnetSAModulePWCLONet(mlp=list(mlp), npoint=npoint, nsample=nsample), name)
     xyz = cloud(1, 3, n)
     feat = torch.randn(3, c, n, generator=torch.Generator().manual_seed(2)) if c else None
     ref_xyz, ref_feat = M.set_abstraction(osd, name, npoint, nsample, xyz, feat)
     idx = O.knn_point_with_dist(nsample, xyz, ref_xyz)[1]
-    fsa = fused.FusedSA(mod.to(cuda))
-    out = fsa(xyz.to(cuda), ref_xyz.to(cuda),
-              feat.permute(0, 2, 1).contiguous().to(cuda) if c else None, idx.to(cuda))
+    feat_pm = feat.permute(0, 2, 1).contiguous().to(cuda) if c else None
+    if hoist:       # layer 1's feature part precomputed per point (csrc/fused_hoisted.hip)
+        fsa = fused.FusedSAHoisted(mod.to(cuda))
+        pre = fused.run_linear_jobs(fsa.jobs(feat_pm))[0] if c else None
+        out = fsa(xyz.to(cuda), ref_xyz.to(cuda), pre, idx.to(cuda))
+    else:
+        out = fused.FusedSA(mod.to(cuda))(xyz.to(cuda), ref_xyz.to(cuda), feat_pm, idx.to(cuda))
     close(out.permute(0, 2, 1), ref_feat)
 
 
@@ -70,7 +75,8 @@ pm = lambda t: t.permute(0, 2, 1).contiguous()      # (B,C,N) <-> (B,N,C)
 
 
 @pytest.mark.parametrize("c2,n2,n1", [(32, 512, 128), (16, 333, 90), (64, 256, 64)])
-def test_fused_set_upconv(cuda, c2, n2, n1):
+@pytest.mark.parametrize("hoist", [False, True])
+def test_fused_set_upconv(cuda, c2, n2, n1, hoist):
     name = "pose_warp_refinement_2.setupconv_features"
     mod, osd = filled(PointnetFPModulePWCLONet(nsample=8, mlp=[64, 128, 64], post_mlp=[64 + c2, 64],
                                                radius=0.2, knn=True, use_xyz=True, bn=True), name)
@@ -79,14 +85,20 @@ def test_fused_set_upconv(cuda, c2, n2, n1):
     f2, f1 = torch.randn(2, c2, n2, generator=g), torch.randn(2, 64, n1, generator=g)
     ref = M.set_upconv(osd, name, 8, xyz2, xyz1, f2, f1)
     idx = O.knn_point_with_dist(8, xyz1, xyz2)[1]
-    up = fused.FusedUpconv(mod.to(cuda))
-    out = up(xyz2.to(cuda), xyz1.to(cuda), pm(f2).to(cuda), pm(f1).to(cuda), idx.to(cuda))
+    if hoist:
+        up = fused.FusedUpconvHoisted(mod.to(cuda))
+        (pre,) = fused.run_linear_jobs(up.jobs(pm(f1).to(cuda)))
+        out = up(xyz2.to(cuda), xyz1.to(cuda), pm(f2).to(cuda), pre, idx.to(cuda))
+    else:
+        up = fused.FusedUpconv(mod.to(cuda))
+        out = up(xyz2.to(cuda), xyz1.to(cuda), pm(f2).to(cuda), pm(f1).to(cuda), idx.to(cuda))
     close(pm(out), ref)
 
 
 @pytest.mark.parametrize("nq,ns,c,s,n", [(32, 4, 64, 256, 256), (6, 4, 64, 256, 256), (6, 4, 32, 512, 512),
                                           (6, 4, 16, 301, 280), (32, 4, 64, 70, 90)])
-def test_fused_cost_volume(cuda, nq, ns, c, s, n):
+@pytest.mark.parametrize("hoist", [False, True])
+def test_fused_cost_volume(cuda, nq, ns, c, s, n, hoist):
     name = "cost_volume"
     mod, osd = filled(CostVolume(nsample=ns, nsample_q=nq, in_channel1=c, in_channel2=c,
                                  mlp1=[128, 64, 64], mlp2=[128, 64]), name)
@@ -95,9 +107,15 @@ def test_fused_cost_volume(cuda, nq, ns, c, s, n):
     p1, p2 = torch.randn(2, c, s, generator=g), torch.randn(2, c, n, generator=g)
     taps = {}
     ref = M.cost_volume(osd, name, ns, nq, x1, p1, x2, p2, taps, "cv")
-    cv = fused.FusedCostVolume(mod.to(cuda))
-    out = cv(pm(x1).to(cuda), pm(p1).to(cuda), pm(x2).to(cuda), pm(p2).to(cuda),
-             idx_q=taps["cv.idx_q"].to(cuda), idx=taps["cv.idx"].to(cuda))
+    if hoist:
+        cv = fused.FusedCostVolumeHoisted(mod.to(cuda))
+        u, v, u2 = fused.run_linear_jobs(cv.jobs(pm(p1).to(cuda), pm(p2).to(cuda)))
+        out = cv(pm(x1).to(cuda), pm(x2).to(cuda), u, v, u2,
+                 idx_q=taps["cv.idx_q"].to(cuda), idx=taps["cv.idx"].to(cuda))
+    else:
+        cv = fused.FusedCostVolume(mod.to(cuda))
+        out = cv(pm(x1).to(cuda), pm(p1).to(cuda), pm(x2).to(cuda), pm(p2).to(cuda),
+                 idx_q=taps["cv.idx_q"].to(cuda), idx=taps["cv.idx"].to(cuda))
     close(pm(out), ref, rel=2e-5)
 
 
@@ -153,8 +171,10 @@ def _net(dev):
     return net.to(dev).eval()
 
 
+@pytest.mark.parametrize("hoist", ["0", "1"])
 @pytest.mark.parametrize("case", ["n1024_b2", "n8192_b1"])
-def test_fused_network_against_reference_golden(cuda, case):
+def test_fused_network_against_reference_golden(cuda, case, hoist, monkeypatch):
+    monkeypatch.setenv("PWCLO_HOIST", hoist)      # section-3 kernels vs hoisted first layers (section 4)
     z = np.load(os.path.join(GOLDEN, "pwclonet_%s.npz" % case))
     meta = json.loads(str(z["meta"]))
     if meta["generator"] == "uniform":
@@ -165,6 +185,7 @@ def test_fused_network_against_reference_golden(cuda, case):
     x2 = torch.from_numpy(pc2[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
     net = _net(cuda)
     fnet = fused.FusedPWCLONet(net)
+    assert fnet.hoist == (hoist == "1")
     pose, inter = fnet(x1, x2, return_intermediates=True)
     ref = torch.from_numpy(z["pose_params"])
     err = (pose.cpu() - ref).abs().max().item()
