@@ -134,7 +134,12 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
     if (XYZ_ONLY) {
       mlp_layer<1, B1, P, true>(h1, in, lds_w, lane);
     } else {
-      mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane, [&](int o, int p) { return ld4(prow[p] + 16 * o); });
+      // all seed rows are requested before the first MFMA: one exposed memory latency per tile
+#pragma unroll
+      for (int o = 0; o < B1; ++o)
+#pragma unroll
+        for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
+      mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });
     }
     mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
     mlp_layer<B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
@@ -199,7 +204,11 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
       prow[p] = a.pre + ((size_t)b * a.N + nbr) * 128 + 4 * g;
     }
     f32x4 h1[B1][P], h2[B2][P];
-    mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane, [&](int o, int p) { return ld4(prow[p] + 16 * o); });
+#pragma unroll
+    for (int o = 0; o < B1; ++o)
+#pragma unroll
+      for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
+    mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });
     mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
     constexpr int GROUP = KP < 16 ? KP : 16;
 #pragma unroll
@@ -256,8 +265,11 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
       vrow[p] = a.v + ((size_t)b * a.N + nbr) * 128 + 4 * g;
     }
     f32x4 h1[B1][P], h2[B2][P], h3[B3][P];
-    mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane,
-                                   [&](int o, int p) { return ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o); });
+#pragma unroll
+    for (int o = 0; o < B1; ++o)
+#pragma unroll
+      for (int p = 0; p < P; ++p) h1[o][p] = ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o);
+    mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });
     mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
     mlp_layer<B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
 #pragma unroll
@@ -300,9 +312,12 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
       for (int m = 0; m < 4; ++m) val[m][p] = ld4(fr + 16 * m);
     }
     f32x4 enc[4][P], h1[8][P], h2[4][P];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+      for (int p = 0; p < P; ++p) h1[o][p] = ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o);
     mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
-    mlp_layer_init<4, 8, P, true>(h1, enc, lds_w + WX, lane,
-                                  [&](int o, int p) { return ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o); });
+    mlp_layer_init<4, 8, P, true>(h1, enc, lds_w + WX, lane, [&](int o, int p) { return h1[o][p]; });
     mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
     // softmax over the neighbours, weighted sum of the gathered first-aggregate rows
     constexpr int GROUP = KP < 16 ? KP : 16;
@@ -419,7 +434,7 @@ extern "C" void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const f
   const int kp = k > 16 ? 32 : (k > 8 ? 16 : 8);
   constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4) + layer_floats(4, 4));
   static bool a32 = false, a16 = false, a8 = false;
-  if (kp == 32) launch_h<8>(cv_a1_h_kernel<32, 2, 8>, a32, lds, tiles_h(b, s, 32, 2), a);
+  if (kp == 32) launch_h<16>(cv_a1_h_kernel<32, 1, 16>, a32, lds, tiles_h(b, s, 32, 1), a);
   else if (kp == 16) launch_h<16>(cv_a1_h_kernel<16, 1, 16>, a16, lds, tiles_h(b, s, 16, 1), a);
   else launch_h<16>(cv_a1_h_kernel<8, 1, 16>, a8, lds, tiles_h(b, s, 8, 1), a);
   check_launch("cv_fused_a1_h");
