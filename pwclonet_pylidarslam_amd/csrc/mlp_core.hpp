@@ -28,11 +28,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Floats occupied in LDS by one packed layer: NBO*NBI 1-KiB operand tiles + NBO*16 biases.
 constexpr int layer_floats(int nbi, int nbo) { return nbo * nbi * 256 + nbo * 16; }
 
-// Cooperative copy of `nfloats` (multiple of 4) packed floats from global memory into LDS.
+// Cooperative copy of `nfloats` (multiple of 4) packed floats from global memory into LDS, with up
+// to 8 independent 16-byte loads in flight per thread (a one-load-per-trip loop pays the full memory
+// latency per trip: 5-6 us for the 100-130 KB stacks, twice per CU at two workgroup rounds).
+template <int U>
+__device__ __forceinline__ int stage_batch(f32x4 *dst, const f32x4 *__restrict__ src, int i, int n4, int step) {
+  for (; i + (U - 1) * step < n4; i += U * step) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = src[i + u * step];
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[i + u * step] = v[u];
+  }
+  return i;
+}
 __device__ __forceinline__ void stage_weights(float *lds, const float *__restrict__ g, int nfloats) {
   const f32x4 *src = reinterpret_cast<const f32x4 *>(g);
   f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
-  for (int i = threadIdx.x; i < nfloats / 4; i += blockDim.x) dst[i] = src[i];
+  const int n4 = nfloats / 4, step = blockDim.x;
+  int i = stage_batch<8>(dst, src, threadIdx.x, n4, step);
+  i = stage_batch<2>(dst, src, i, n4, step);
+  stage_batch<1>(dst, src, i, n4, step);
 }
 
 // One layer for P pixel blocks.  `w` points at the layer's packed weights in LDS.

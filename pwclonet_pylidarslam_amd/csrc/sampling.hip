@@ -218,7 +218,9 @@ static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float 
                            float *new_xyz) {
   const size_t table_bytes = FPS_SLOT_BYTES + (size_t)n * sizeof(float4);
   hipStream_t st = current_stream();
-  if (table_bytes <= 160 * 1024) {
+  static int use_table = -1;
+  if (use_table < 0) { const char *e = getenv("PWCLO_FPS_TABLE"); use_table = e ? atoi(e) : 1; }
+  if (table_bytes <= 160 * 1024 && (use_table || table_bytes <= 64 * 1024)) {
     auto kern = fps_reg_kernel<T, E, I, true>;
     static bool big_lds_enabled = false;  // per instantiation; raises the 64 KiB dynamic-LDS default
     if (table_bytes > 64 * 1024 && !big_lds_enabled) {

@@ -35,7 +35,7 @@ def run(tag, inflight):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 40
     print(f"{tag:24s} inflight={inflight}: {dt*1e3:6.3f} ms/step  {32/dt:7.0f} pairs/s", flush=True)
 
-for inflight in (1, 2):
+for inflight in (1, 2, 3):
     fused.fps_with_xyz, fused.knn = orig["fps"], orig["knn"]
     run("full", inflight)
     fused.fps_with_xyz = fake_fps; run("no FPS", inflight); fused.fps_with_xyz = orig["fps"]
