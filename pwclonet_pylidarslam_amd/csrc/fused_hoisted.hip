@@ -20,15 +20,28 @@ static int fh_tuning(const char *name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-// 16-channel geometry block [p(3), q(3), q-p(3), |q-p|, 0 x 6] (costvolume.py:92-105), lane group g.
+// Geometry inputs are laid out "k-step major": logical channel c sits at lane group c % 4, component
+// c / 4, i.e. MFMA k-step c / 4 (a 16x16x4 instruction consumes component r of all four lane
+// groups), so n real channels need only ceil(n / 4) of the block's four k-steps (KS below;
+// fused.py: kstep_major_map packs the weights to match).
+// cost volume: [p(3), q(3), q-p(3), |q-p|] (costvolume.py:92-105) -> 3 k-steps.
 __device__ __forceinline__ f32x4 geometry_block_h(const float *p, const float *q, int g) {
   const float px = p[0], py = p[1], pz = p[2], qx = q[0], qy = q[1], qz = q[2];
   const float dx = qx - px, dy = qy - py, dz = qz - pz;
   const float euc = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-20f);
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (g == 0) v = f32x4{px, py, pz, qx};
-  if (g == 1) v = f32x4{qy, qz, dx, dy};
-  if (g == 2) v = f32x4{dz, euc, 0.f, 0.f};
+  f32x4 v = {px, qy, dz, 0.f};                   // channels 0, 4, 8
+  if (g == 1) v = f32x4{py, qz, euc, 0.f};       // 1, 5, 9
+  if (g == 2) v = f32x4{pz, dx, 0.f, 0.f};       // 2, 6
+  if (g == 3) v = f32x4{qx, dy, 0.f, 0.f};       // 3, 7
+  return v;
+}
+// [diff(3)] (one k-step) or, at level 0, [diff(3), neighbour xyz(3)] (two k-steps).
+__device__ __forceinline__ f32x4 diff_block_h(float dx, float dy, float dz, float qx, float qy, float qz,
+                                              bool with_q, int g) {
+  f32x4 v = {dx, with_q ? qy : 0.f, 0.f, 0.f};
+  if (g == 1) v = f32x4{dy, with_q ? qz : 0.f, 0.f, 0.f};
+  if (g == 2) v = f32x4{dz, 0.f, 0.f, 0.f};
+  if (g == 3) v = f32x4{with_q ? qx : 0.f, 0.f, 0.f, 0.f};
   return v;
 }
 
@@ -124,22 +137,19 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
       const float *c = a.new_xyz + ((size_t)b * a.S + s) * 3;
       const float *q = a.xyz + ((size_t)b * a.N + nbr) * 3;
       const float qx = q[0], qy = q[1], qz = q[2];
-      f32x4 geo = {0.f, 0.f, 0.f, 0.f};
-      if (g == 0) geo = f32x4{qx - c[0], qy - c[1], qz - c[2], XYZ_ONLY ? qx : 0.f};
-      if (XYZ_ONLY && g == 1) geo = f32x4{qy, qz, 0.f, 0.f};
-      in[0][p] = geo;
+      in[0][p] = diff_block_h(qx - c[0], qy - c[1], qz - c[2], qx, qy, qz, XYZ_ONLY, g);
       prow[p] = XYZ_ONLY ? nullptr : a.pre + ((size_t)b * a.N + nbr) * C1 + 4 * g;
     }
     f32x4 h1[B1][P], h2[B2][P], h3[B3][P];
     if (XYZ_ONLY) {
-      mlp_layer<1, B1, P, true>(h1, in, lds_w, lane);
+      mlp_layer<1, B1, P, true, 2>(h1, in, lds_w, lane);          // 6 real inputs
     } else {
       // all seed rows are requested before the first MFMA: one exposed memory latency per tile
 #pragma unroll
       for (int o = 0; o < B1; ++o)
 #pragma unroll
         for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
-      mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });
+      mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
     }
     mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
     mlp_layer<B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
@@ -198,9 +208,7 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
       const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
       const float *c = a.xyz2 + ((size_t)b * a.S + s) * 3;
       const float *q = a.xyz1 + ((size_t)b * a.N + nbr) * 3;
-      f32x4 d = {0.f, 0.f, 0.f, 0.f};
-      if (g == 0) d = f32x4{q[0] - c[0], q[1] - c[1], q[2] - c[2], 0.f};
-      in[0][p] = d;
+      in[0][p] = diff_block_h(q[0] - c[0], q[1] - c[1], q[2] - c[2], 0.f, 0.f, 0.f, false, g);
       prow[p] = a.pre + ((size_t)b * a.N + nbr) * 128 + 4 * g;
     }
     f32x4 h1[B1][P], h2[B2][P];
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
     for (int o = 0; o < B1; ++o)
 #pragma unroll
       for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
-    mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });
+    mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
     mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
     constexpr int GROUP = KP < 16 ? KP : 16;
 #pragma unroll
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
     for (int o = 0; o < B1; ++o)
 #pragma unroll
       for (int p = 0; p < P; ++p) h1[o][p] = ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o);
-    mlp_layer_init<1, B1, P, true>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });
+    mlp_layer_init<1, B1, P, true, 3>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // geometry(10)
     mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
     mlp_layer<B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
 #pragma unroll
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
     for (int o = 0; o < 8; ++o)
 #pragma unroll
       for (int p = 0; p < P; ++p) h1[o][p] = ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o);
-    mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
+    mlp_layer<1, 4, P, true, 3>(enc, geo, lds_w, lane);
     mlp_layer_init<4, 8, P, true>(h1, enc, lds_w + WX, lane, [&](int o, int p) { return h1[o][p]; });
     mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
     // softmax over the neighbours, weighted sum of the gathered first-aggregate rows

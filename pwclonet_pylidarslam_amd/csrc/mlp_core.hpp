@@ -58,7 +58,9 @@ __device__ __forceinline__ void stage_weights(float *lds, const float *__restric
 // hoisting every later read as well (which spilled).
 // `init(o, p)` seeds the accumulator of output block o / pixel block p: the layer's bias, or --
 // for hoisted first layers -- the per-point partial products gathered from memory (see below).
-template <int NBI, int NBO, int P, bool RELU, typename Init>
+// KS < 4 runs only the first KS 4-channel k-steps of every input block: for a lone geometry block
+// whose channels 4*KS.. are zero padding (3 or 6 or 10 real inputs) the other MFMAs multiply zeros.
+template <int NBI, int NBO, int P, bool RELU, int KS = 4, typename Init>
 __device__ __forceinline__ void mlp_layer_init(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
                                                const float *w, int lane, Init init) {
   const float *wl = w + lane * 4;
@@ -74,7 +76,7 @@ __device__ __forceinline__ void mlp_layer_init(f32x4 (&out)[NBO][P], const f32x4
       for (int p = 0; p < P; ++p) acc[p] = init(o, p);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < KS; ++r) {
 #pragma unroll
       for (int p = 0; p < P; ++p)
         acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[r], in[m][p][r], acc[p], 0, 0, 0);
@@ -96,11 +98,11 @@ __device__ __forceinline__ void mlp_layer_init(f32x4 (&out)[NBO][P], const f32x4
   }
 }
 
-template <int NBI, int NBO, int P, bool RELU>
+template <int NBI, int NBO, int P, bool RELU, int KS = 4>
 __device__ __forceinline__ void mlp_layer(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
                                           const float *w, int lane) {
   const float *bias = w + NBO * NBI * 256 + 4 * (lane >> 4);
-  mlp_layer_init<NBI, NBO, P, RELU>(out, in, w, lane, [&](int o, int) {
+  mlp_layer_init<NBI, NBO, P, RELU, KS>(out, in, w, lane, [&](int o, int) {
     return *reinterpret_cast<const f32x4 *>(bias + 16 * o);
   });
 }

@@ -333,6 +333,17 @@ def run_linear_jobs(jobs):
     return outs
 
 
+def kstep_major_map(n):
+    """Physical order of a lone geometry block for the hoisted kernels: logical channel c at lane
+    group c % 4, component c // 4 (position 4 * (c % 4) + c // 4), so only ceil(n / 4) MFMA k-steps
+    carry data (csrc/fused_hoisted.hip: geometry_block_h / diff_block_h)."""
+    out = []
+    for pos in range(16):
+        c = 4 * (pos % 4) + pos // 4
+        out.append(c if c < n else -1)
+    return out
+
+
 def _zeros_like_bias(w):
     return torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
 
@@ -361,10 +372,10 @@ class FusedSAHoisted:
         if self.c_feat:
             # original order [xyz_diff(3), feat(C)] (pointnet2_modules.py:222)
             self.pre_job = LinearJob(_pad_rows(w1[:, 3:], 16 * nbo1), _pad_rows(b1, 16 * nbo1))
-            first = pack_layer(w1[:, :3], _zeros_like_bias(w1), [0, 1, 2] + [-1] * 13, nbo1)
+            first = pack_layer(w1[:, :3], _zeros_like_bias(w1), kstep_major_map(3), nbo1)
         else:
             self.pre_job = None
-            first = pack_layer(w1, b1, [0, 1, 2, 3, 4, 5] + [-1] * 10, nbo1)
+            first = pack_layer(w1, b1, kstep_major_map(6), nbo1)
         rest, widths = _pack_rest(layers[1:], w1.shape[0])
         self.packed = torch.cat([first] + rest).contiguous()
         self.widths = [16 * nbo1] + widths
@@ -403,7 +414,7 @@ class FusedUpconvHoisted:
         w1, b1 = fold_conv_bn(layers[0])
         assert w1.shape == (128, 67), "set-upconv kernel is built for 64-channel coarse features"
         self.pre_job = LinearJob(w1[:, :64], b1)                     # original order [feat(64), diff(3)], :490
-        first = pack_layer(w1[:, 64:67], _zeros_like_bias(w1), [0, 1, 2] + [-1] * 13, 8)
+        first = pack_layer(w1[:, 64:67], _zeros_like_bias(w1), kstep_major_map(3), 8)
         rest, widths = _pack_rest(layers[1:], 128)
         assert widths == [64]
         self.packed = torch.cat([first] + rest).contiguous()
@@ -438,7 +449,7 @@ class FusedCostVolumeHoisted:
         w1, b1 = fold_conv_bn(la[0])                                   # [geo(10) | feat1 (C) | feat2 (C)]
         self.job_u = LinearJob(w1[:, 10:10 + c], b1)
         self.job_v = LinearJob(w1[:, 10 + c:10 + 2 * c], _zeros_like_bias(w1))
-        first = pack_layer(w1[:, :10], _zeros_like_bias(w1), geo, 8)
+        first = pack_layer(w1[:, :10], _zeros_like_bias(w1), kstep_major_map(10), 8)
         rest, widths = _pack_rest(la[1:], 128)
         assert widths == [64, 64]
         self.w_a1 = torch.cat([first] + rest).contiguous()
@@ -446,7 +457,7 @@ class FusedCostVolumeHoisted:
         w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)))
         assert wd == [64] and wd2 == [128, 64]
         self.w_a2 = torch.cat((wx1, w2)).contiguous()
-        wx2, _ = pack_stack(module.mlp_conv_xyz_2, geo)
+        wx2, _ = pack_stack(module.mlp_conv_xyz_2, kstep_major_map(10))
         lb = list(module.mlp3_convs)
         w3, b3 = fold_conv_bn(lb[0])                                   # [enc2 (64) | feat1 (C) | first (64)]
         self.job_u2 = LinearJob(w3[:, 64:64 + c], b3)
