@@ -11,14 +11,15 @@ are replicas ("weak" scaling); the only collectives are the barrier around the t
 the MAX-reduce of its duration.  Rank 0 prints ONE JSON line.
 
 Timed region: W warm-up steps, then exactly K steps between two fences (device sync + barrier +
-device sync).  By default a step is one hipGraph replay and two batches are kept in flight
-(`--inflight 2`; DESIGN.md "Launch structure").
+device sync).  By default a step is one hipGraph replay and four batches are kept in flight
+(`--inflight 4`, each a forward over its own batch of 32; DESIGN.md "Launch structure").
 
-`roofline`: after the timed region the same step runs once more eagerly with HIP events around
-every launch of the library (events recorded on the launch stream); the object reports the
-dominant kernel family by time -- the register-resident MFMA MLP stack (csrc/mlp_core.hpp, all
-fused_* kernels) -- as algorithmic FLOP / measured time against the fp32 MFMA peak, and `kernels`
-lists the other families with the bound that applies to them.  `cpu_baseline`: the CPU oracle
+`roofline`: after the timed region the same step runs three more times eagerly with HIP events
+around every launch of the library (events recorded on the launch stream); the object reports the
+dominant MFMA kernel by time (one template instantiation, named as rocprofv3 names it) as
+algorithmic FLOP / measured time against the fp32 MFMA peak, `traffic` from the committed PMC
+passes (profiles/pmc_traffic.json), `mlp_family` the same figure over every MFMA-stack launch, and
+`kernels` lists the other families (FPS, knn) with the bound that applies to them.  `cpu_baseline`: the CPU oracle
 (bit-identical to the imported reference) on a few B=1 pairs on this box's host cores.
 """
 import argparse
@@ -27,11 +28,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import pwclonet_pylidarslam_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime starts)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from pwclonet_pylidarslam_amd import _lib, dist_util, synthetic  # noqa: E402
 from pwclonet_pylidarslam_amd.pwclonet import PWCLONet  # noqa: E402
@@ -77,40 +79,77 @@ class LaunchProfiler:
             d["launches"] += 1
             for k in ("flops", "bytes", "units", "iters"):
                 d[k] += meta.get(k, 0)
-            bn = d["by_name"].setdefault(name, [0.0, 0])
-            bn[0] += ms
-            bn[1] += 1
+            bn = d["by_name"].setdefault(meta.get("kernel", name), {"ms": 0.0, "launches": 0, "flops": 0.0,
+                                                                     "bytes": 0.0})
+            bn["ms"] += ms
+            bn["launches"] += 1
+            bn["flops"] += meta.get("flops", 0)
+            bn["bytes"] += meta.get("bytes", 0)
         return fam
 
 
-def instrumented_pass(net, x1, x2):
-    """One eager forward of the same step with per-launch HIP events (graphs cannot be timed
-    kernel by kernel from inside the process)."""
+def instrumented_pass(net, x1, x2, passes=3):
+    """`passes` eager forwards of the same step with per-launch HIP events (graphs cannot be timed
+    kernel by kernel from inside the process); returns the per-family summary of their average."""
     prof = LaunchProfiler()
     with torch.no_grad():
         net(x1, None, x2, None)           # warm (allocator, one-time attributes)
         torch.cuda.synchronize()
         _lib.profiler = prof
         try:
-            net(x1, None, x2, None)
+            for _ in range(passes):
+                net(x1, None, x2, None)
         finally:
             _lib.profiler = None
     torch.cuda.synchronize()
-    return prof.summary()
+    fam = prof.summary()
+    for d in fam.values():                # totals -> per-step averages
+        for k in ("ms", "flops", "bytes", "units"):
+            d[k] /= passes
+        d["launches"] //= passes
+        d["iters"] //= passes
+        for v in d["by_name"].values():
+            for k in ("ms", "flops", "bytes"):
+                v[k] /= passes
+            v["launches"] //= passes
+    return fam
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs, corrected as MI355X_MICROARCH.md's HBM
+    section prescribes).  Counters cannot be read from inside the process: None if not collected."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def roofline_objects(fam):
     total_ms = sum(d["ms"] for d in fam.values()) or 1.0
-    mlp = fam.get("mlp", {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
-    tf = mlp["flops"] / 1e12 / (mlp["ms"] / 1e3) if mlp["ms"] > 0 else 0.0
-    roof = {"kernel": "mlp_core MFMA stack (sa/upconv/pointwise/cv_a1/cv_a2/cv_b kernels)",
-            "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "launches": mlp["launches"],
-            "avg_launch_us": 1e3 * mlp["ms"] / max(mlp["launches"], 1),
-            "algorithmic_gflop_per_step": mlp["flops"] / 1e9,
-            "algorithmic_mb_per_step": mlp["bytes"] / 1e6,
-            "share_of_kernel_time": mlp["ms"] / total_ms,
-            "timing": "HIP events on the launch stream, one eager pass after the timed region"}
+    mlp = fam.get("mlp", {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "by_name": {}})
+    # the dominant kernel: the MFMA-stack kernel (one template instantiation) with the most time
+    name, dom = max(mlp["by_name"].items(), key=lambda kv: kv[1]["ms"], default=("none", None))
+    dom = dom or {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0}
+    n = max(dom["launches"], 1)
+    tf = dom["flops"] / 1e12 / (dom["ms"] / 1e3) if dom["ms"] > 0 else 0.0
+    fam_tf = mlp["flops"] / 1e12 / (mlp["ms"] / 1e3) if mlp["ms"] > 0 else 0.0
+    traffic = pmc_traffic(name)
+    roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+            "launches_per_step": dom["launches"], "avg_launch_us": 1e3 * dom["ms"] / n,
+            "algorithmic_gflop_per_launch": dom["flops"] / 1e9 / n,
+            "algorithmic_mb_per_launch": dom["bytes"] / 1e6 / n,
+            "share_of_kernel_time": dom["ms"] / total_ms,
+            "timing": "HIP events on the launch stream, average of 3 eager passes after the timed region "
+                      "(isolated launches; in the pipelined timed region kernels of different batches share CUs)",
+            "mlp_family": {"kernels": "every mlp_core MFMA stack kernel (sa/upconv/pointwise/cv_a1/cv_a2/cv_b/"
+                                      "linear_jobs)", "launches_per_step": mlp["launches"],
+                           "ms_per_step": mlp["ms"], "algorithmic_gflop_per_step": mlp["flops"] / 1e9,
+                           "achieved_tflops": fam_tf, "frac": fam_tf / MFMA_F32_PEAK_TFLOPS,
+                           "share_of_kernel_time": mlp["ms"] / total_ms}}
     kernels = {}
     if "fps" in fam:
         d = fam["fps"]
@@ -161,9 +200,13 @@ def main():
                     help="host = the reference's log_dict on the host (lazy: built when read)")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph = replay one captured hipGraph per step (default); eager = Python launches")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="batches in flight (graph launch only): 2 = one batch's FPS chain overlaps the "
-                         "other's neighbour-search/MLP kernels; 1 = strictly serial steps")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="batches in flight (graph launch only), each on its own stream: one batch's FPS chain "
+                         "overlaps the others' neighbour-search/MLP kernels; 1 = strictly serial steps")
+    ap.add_argument("--pipeline", default="whole", choices=["staged", "whole"],
+                    help="with --inflight > 1: staged = sampling chains of successive batches back to back on "
+                         "one stream, the rest on two others (graphed.StagedPipeline, --inflight = slots); "
+                         "whole = one whole-forward graph per slot (graphed.PipelinedForward)")
     ap.add_argument("--unfused", action="store_true",
                     help="reference-shaped module graph on the HIP ops (torch conv/BN) instead of the fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,8 +230,11 @@ def main():
 
     pipe = None
     if args.launch == "graph" and args.inflight > 1:
-        from pwclonet_pylidarslam_amd.graphed import PipelinedForward
-        pipe = PipelinedForward(net, depth=args.inflight)
+        from pwclonet_pylidarslam_amd.graphed import PipelinedForward, StagedPipeline
+        if args.pipeline == "staged" and not args.unfused:
+            pipe = StagedPipeline(net, slots=args.inflight)
+        else:
+            pipe = PipelinedForward(net, depth=args.inflight)
 
         def step():
             return pipe(x1, x2)[0]
@@ -228,6 +274,8 @@ def main():
                        "global_batch": world * args.batch, "npoints": args.npoints,
                        "parallelism": "replicas x%d (no forward collective)" % world,
                        "launch": args.launch, "batches_in_flight": args.inflight if pipe else 1,
+                       "pipeline": (args.pipeline if pipe else "none"),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "kernels": "module graph + torch conv/BN" if args.unfused
                        else "fused gather+MFMA-MLP kernels (BN folded)",
                        "log_dict": args.log_mode + " (lazy)"},

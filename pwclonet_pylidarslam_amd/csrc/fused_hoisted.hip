@@ -266,7 +266,7 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
       const bool valid = pm.s < a.S;
       const int s = valid ? pm.s : a.S - 1;
       const int k = pm.k < a.K ? pm.k : 0;
-      pixv[p] = valid ? pix : -1;
+      pixv[p] = (valid && pm.k < a.K) ? pix : -1;      // padded slots are never read back (cv_a2)
       const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
       in[0][p] = geometry_block_h(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
       urow[p] = a.u + ((size_t)b * a.S + s) * 128 + 4 * g;

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(W * 64) void cv_a1_kernel(CVArgs a) {
       const bool valid = pm.s < a.S;
       const int s = valid ? pm.s : a.S - 1;
       const int k = pm.k < a.K ? pm.k : 0;
-      pixv[p] = valid ? pix : -1;
+      pixv[p] = (valid && pm.k < a.K) ? pix : -1;      // padded slots are never read back (cv_a2)
       const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
       in[0][p] = geometry_block(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
       load_row_blocks<CB>(&in[1][p], P, a.feat1 + ((size_t)b * a.S + s) * C, g);
@@ -286,7 +286,8 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
       sq[p] = valid ? s : -1;
       const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
       geo[0][p] = geometry_block(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
-      const int pixc = valid ? pix : pix_per_cloud - 1;
+      // padded slots (masked below) re-read slot 0's row: a1 does not write them, no extra traffic
+      const int pixc = valid ? pix - (padded[p] ? pm.k : 0) : pix_per_cloud - KP;
       load_row_blocks<4>(&cat[4][p], P, a.pix + ((size_t)b * pix_per_cloud + pixc) * 64, g);
     }
     f32x4 enc[4][P];

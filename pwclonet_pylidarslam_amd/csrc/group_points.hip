@@ -28,11 +28,33 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, 
     const int p = (blockIdx.x * GP_THREADS + threadIdx.x) * 4;
     if (p >= P) return;
     const int4 ii = *reinterpret_cast<const int4 *>(ib + p);
-    for (int l = c0; l < c1; ++l) {
-      const float *row = points + ((size_t)b * c + l) * n;
-      float4 v;
-      v.x = row[ii.x]; v.y = row[ii.y]; v.z = row[ii.z]; v.w = row[ii.w];
-      *reinterpret_cast<float4 *>(out + ((size_t)b * c + l) * P + p) = v;
+    const float *row0 = points + ((size_t)b * c + c0) * n;
+    float *out0 = out + ((size_t)b * c + c0) * P + p;
+    if (c1 - c0 == GP_CH_PER_BLOCK) {
+      // full channel slice: all 32 gathers are in flight before the first store; the output is a
+      // pure stream (never re-read by this kernel) and goes out non-temporal so that it does not
+      // evict the channel rows being gathered from L2
+      float4 v[GP_CH_PER_BLOCK];
+#pragma unroll
+      for (int l = 0; l < GP_CH_PER_BLOCK; ++l) {
+        const float *row = row0 + (size_t)l * n;
+        v[l].x = row[ii.x]; v[l].y = row[ii.y]; v[l].z = row[ii.z]; v[l].w = row[ii.w];
+      }
+#pragma unroll
+      for (int l = 0; l < GP_CH_PER_BLOCK; ++l) {
+        float *o = out0 + (size_t)l * P;
+        __builtin_nontemporal_store(v[l].x, o + 0);
+        __builtin_nontemporal_store(v[l].y, o + 1);
+        __builtin_nontemporal_store(v[l].z, o + 2);
+        __builtin_nontemporal_store(v[l].w, o + 3);
+      }
+    } else {
+      for (int l = 0; l < c1 - c0; ++l) {
+        const float *row = row0 + (size_t)l * n;
+        float4 v;
+        v.x = row[ii.x]; v.y = row[ii.y]; v.z = row[ii.z]; v.w = row[ii.w];
+        *reinterpret_cast<float4 *>(out0 + (size_t)l * P) = v;
+      }
     }
   } else {
     const int p = blockIdx.x * GP_THREADS + threadIdx.x;

@@ -8,6 +8,8 @@ where ``W' = W * gamma/sqrt(var+eps)``, ``bias' = beta - mean*gamma/sqrt(var+eps
 BatchNorm folded into the 1x1 convolution) and ``phys`` maps the kernel's physical input
 channel order (16-channel blocks, one source per block) to the layer's original input channels.
 """
+import contextlib
+
 import torch
 
 from . import _lib
@@ -255,7 +257,8 @@ class FusedCostVolume:
         _lib.call("cv_fused_a1_kernel_wrapper", dev, B, N, S, kq, self.c, _p(xyz1), _p(feat1), _p(xyz2),
                   _p(feat2), _p(idx_q), _p(self.w_a1), _p(pix))
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", flops=2.0 * B * S * kq * self.macs_a2,
+        _lib.annotate(family="mlp", kernel="cv_a2_kernel<%s>" % {32: "32, 2, 8", 16: "16, 1, 16", 8: "8, 1, 16"}[kp],
+                      flops=2.0 * B * S * kq * self.macs_a2,
                       bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
                   _p(self.w_a2), _p(pix), _p(first))
@@ -488,7 +491,8 @@ class FusedCostVolumeHoisted:
         _lib.call("cv_fused_a1_h_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(u), _p(xyz2), _p(v), _p(idx_q),
                   _p(self.w_a1), _p(pix))
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", flops=2.0 * B * S * kq * self.macs_a2,
+        _lib.annotate(family="mlp", kernel="cv_a2_kernel<%s>" % {32: "32, 2, 8", 16: "16, 1, 16", 8: "8, 1, 16"}[kp],
+                      flops=2.0 * B * S * kq * self.macs_a2,
                       bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
                   _p(self.w_a2), _p(pix), _p(first))
@@ -526,7 +530,7 @@ class _Branches:
     def fork(self, k):
         """Context: run the body on side stream k, after everything queued on main so far."""
         if not self.on:
-            return torch.cuda.stream(self.main)
+            return contextlib.nullcontext()
         ev = torch.cuda.Event()
         ev.record(self.main)
         self.side[k].wait_event(ev)
@@ -604,10 +608,14 @@ class FusedPWCLONet:
         return q, t, emb, mask
 
     @torch.no_grad()
-    def __call__(self, xyz_f1, xyz_f2, return_intermediates=False):
-        """xyz_f1, xyz_f2 (B,3,N) -> pose_params (B,4,7) [+ dict of point-major intermediates]."""
+    def sample(self, xyz_f1, xyz_f2, br=None):
+        """Stage 1 -- everything that depends on the input coordinates only: both frames point-major
+        in one (2B,N,3) batch and the furthest-point-sampling chain of the four pyramid levels.
+        Returns the state ``rest`` consumes.  (Split out so that a pipeline can run the sampling
+        chains of successive batches back to back on one stream: graphed.StagedPipeline.)"""
         B, _, N0 = xyz_f1.shape
-        br = _Branches(xyz_f1.device, self.branch and torch.cuda.is_current_stream_capturing())
+        if br is None:
+            br = _Branches(xyz_f1.device, False)
         x = torch.empty((2 * B, N0, 3), dtype=torch.float32, device=xyz_f1.device)  # both frames, point-major
         _lib.call("ingest_pairs_kernel_wrapper", x.device, B, N0, _p(xyz_f1.contiguous()),
                   _p(xyz_f2.contiguous()), _p(x))
@@ -620,6 +628,12 @@ class FusedPWCLONet:
                 _, src = br.hold(*fps_with_xyz(src, npoint))
                 samples.append(src)
                 ready.append(br.mark(0))
+        return dict(B=B, x=x, samples=samples, ready=ready, br=br)
+
+    @torch.no_grad()
+    def rest(self, state, return_intermediates=False):
+        """Stage 2 -- neighbour search, feature pyramid, cost volumes, pose refinement."""
+        B, x, samples, ready, br = state["B"], state["x"], state["samples"], state["ready"], state["br"]
         f = None
         lv = []
         for lvl, (fsa, (npoint, nsample)) in enumerate(zip(self.sa, self.sa_cfg)):
@@ -654,3 +668,9 @@ class FusedPWCLONet:
             return pose, dict(x11=x11, f11=f11, f13=f13, flow=flow, emb4=emb4, mask4=mask4, emb3=emb3,
                               mask3=mask3, emb1=emb1, mask1=mask1, q=(q1, q2, q3, q4), t=(t1, t2, t3, t4))
         return pose
+
+    @torch.no_grad()
+    def __call__(self, xyz_f1, xyz_f2, return_intermediates=False):
+        """xyz_f1, xyz_f2 (B,3,N) -> pose_params (B,4,7) [+ dict of point-major intermediates]."""
+        br = _Branches(xyz_f1.device, self.branch and torch.cuda.is_current_stream_capturing())
+        return self.rest(self.sample(xyz_f1, xyz_f2, br), return_intermediates)

@@ -100,3 +100,94 @@ class PipelinedForward:
     def wait_all(self):
         for s in self.streams or []:
             s.synchronize()
+
+
+class StagedPipeline:
+    """Throughput pipeline that never runs two sampling chains at once.
+
+    A forward is captured as TWO graphs per slot: F = ingest + the furthest-point-sampling chain
+    (depends on the input coordinates only; 64 workgroups that each pin a whole CU through their
+    LDS table, latency-bound, ~2.5 ms at batch 32) and R = everything else (neighbour search, MFMA
+    stacks, pose heads).  All F graphs are replayed on ONE stream, in batch order, so the chains of
+    successive batches run back to back on the same 64 CUs; the R graphs alternate between two
+    other streams and fill the remaining CUs.  With whole-forward graphs (``PipelinedForward``) two
+    batches regularly sit in their F phase together (128 CUs pinned, the rest idle) or in their R
+    phase together (no sampling in flight); here exactly one chain is in flight at any time.
+    F(i) -> R(i) and R(i) -> F(i + slots) (buffer reuse) are event edges.
+
+    ``pipe(xyz_f1, xyz_f2) -> (pose, slot)``: pose is the slot's static output, valid after
+    ``wait(slot)``; a slot is reused every `slots` calls."""
+
+    def __init__(self, net, slots=3, warmup=2):
+        assert not net.training and getattr(net, "_fused", None) is not None, \
+            "StagedPipeline needs an eval-mode net after prepare_fused()"
+        self.net, self.nslots, self.warmup = net, slots, warmup
+        self._slots = None
+        self._i = 0
+
+    def _capture_slot(self, xyz_f1, xyz_f2):
+        fused = self.net._fused
+        s1, s2 = xyz_f1.clone(), xyz_f2.clone()
+        g_f, g_r = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_f), torch.no_grad():
+            state = fused.sample(s1, s2)
+        with torch.cuda.graph(g_r, pool=g_f.pool()), torch.no_grad():   # same pool: `state` stays live
+            pose, inter = fused.rest(state, return_intermediates=True)
+        saved = self.net.log_mode
+        self.net.log_mode = "device" if saved == "host" else saved      # no D2H inside a pipeline
+        try:
+            log = self.net._fused_log_dict(inter)
+        finally:
+            self.net.log_mode = saved
+        return dict(s1=s1, s2=s2, g_f=g_f, g_r=g_r, state=state, pose=pose, log=log, ev_f=None, ev_r=None)
+
+    def _setup(self, xyz_f1, xyz_f2):
+        dev = xyz_f1.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.warmup):          # allocator warm-up + one-time kernel attributes
+                self.net._fused(xyz_f1, xyz_f2)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._slots = [self._capture_slot(xyz_f1, xyz_f2) for _ in range(self.nslots)]
+        self.stream_f = torch.cuda.Stream(device=dev)
+        self.streams_r = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        self._shape = (tuple(xyz_f1.shape), dev)
+
+    def __call__(self, xyz_f1, xyz_f2):
+        if self._slots is None:
+            self._setup(xyz_f1, xyz_f2)
+        assert (tuple(xyz_f1.shape), xyz_f1.device) == self._shape, "StagedPipeline is captured for one input shape"
+        i = self._i
+        self._i += 1
+        k = i % self.nslots
+        sl = self._slots[k]
+        sf, sr = self.stream_f, self.streams_r[i % 2]
+        sf.wait_stream(torch.cuda.current_stream(xyz_f1.device))     # inputs produced on the caller's stream
+        if sl["ev_r"] is not None:
+            sf.wait_event(sl["ev_r"])                                  # the slot's previous batch is done
+        with torch.cuda.stream(sf):
+            sl["s1"].copy_(xyz_f1)
+            sl["s2"].copy_(xyz_f2)
+            sl["g_f"].replay()
+            sl["ev_f"] = torch.cuda.Event()
+            sl["ev_f"].record(sf)
+        sr.wait_event(sl["ev_f"])
+        with torch.cuda.stream(sr):
+            sl["g_r"].replay()
+            sl["ev_r"] = torch.cuda.Event()
+            sl["ev_r"].record(sr)
+        self.last_log_dict = sl["log"]
+        return sl["pose"], k
+
+    def wait(self, slot):
+        ev = self._slots[slot]["ev_r"] if self._slots else None
+        if ev is not None:
+            ev.synchronize()
+
+    def wait_all(self):
+        if self._slots:
+            self.stream_f.synchronize()
+            for s in self.streams_r:
+                s.synchronize()

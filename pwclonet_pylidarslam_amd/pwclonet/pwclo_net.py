@@ -108,6 +108,12 @@ class PWCLONet(nn.Module):
         self._fused = FusedPWCLONet(self)
         return self
 
+    def _fused_log_dict(self, inter):
+        """The reference's log_dict (pwclo_net.py:186-193) from the fused path's point-major tensors."""
+        if self.log_mode == "none":
+            return {}
+        return LazyLogDict(inter["mask1"], inter["x11"], self.log_mode == "host")
+
     def train(self, mode=True):
         if mode:
             self._fused = None      # packed weights would go stale
@@ -128,10 +134,7 @@ class PWCLONet(nn.Module):
     def forward(self, xyz_f1, points_f1, xyz_f2, points_f2, bn_decay=None):
         if self._fused is not None and not self.training and points_f1 is None and points_f2 is None:
             pose, inter = self._fused(xyz_f1, xyz_f2, return_intermediates=True)
-            log_dict = {}
-            if self.log_mode != "none":                        # (B,N,64) / (B,N,3) point-major
-                log_dict = LazyLogDict(inter["mask1"], inter["x11"], self.log_mode == "host")
-            return pose, log_dict
+            return pose, self._fused_log_dict(inter)
         cf = lambda z: z.permute(0, 2, 1).contiguous()
         B = xyz_f1.size(0)
         if (not self.training) and points_f1 is None and points_f2 is None \

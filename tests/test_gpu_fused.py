@@ -220,6 +220,23 @@ def test_fused_forward_is_bitwise_deterministic_and_graph_safe(cuda):
     pipe.wait_all()
     for o, _slot in outs:
         assert torch.equal(o, a)
+    # staged pipeline: sampling graphs on one stream, the rest on two others, 3 slots reused
+    from pwclonet_pylidarslam_amd.graphed import StagedPipeline
+    staged = StagedPipeline(net, slots=3)
+    x1b = x1.flip(0).contiguous()                  # a second, different batch: slots must not mix them up
+    ref_b, _ = net(x1b, None, x2, None)
+    got = []
+    for i in range(8):
+        o, slot = staged(x1b if i % 2 else x1, x2)
+        staged.wait(slot)                           # static output buffer: read before the slot is reused
+        got.append(o.clone())
+    staged.wait_all()
+    for i, o in enumerate(got):
+        assert torch.equal(o, ref_b if i % 2 else a), i
+    outs = [staged(x1, x2) for _ in range(7)]       # free-running (no host waits): last use of each slot
+    staged.wait_all()
+    for o, _slot in outs[-3:]:
+        assert torch.equal(o, a)
     # train() drops the packed weights; the unfused module path then agrees within fp32 noise
     net.train()
     assert net._fused is None
