@@ -174,8 +174,9 @@ void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int c2, int w1
 
 /* CostVolume.forward (PW/costvolume.py:63-190) in three launches.
  * a1: per (query s, neighbour k) pixel: mlp_convs([geometry10 | feat1[s] | feat2[idx]]) -> pix
- *     (b, s*kp, 64), kp = k rounded up to 8/16/32.  xyz1 (b,s,3), feat1 (b,s,c), xyz2 (b,n,3),
- *     feat2 (b,n,c), idx (b,s,k).
+ *     (b, s*kp, 64), kp = k rounded up to 8/16/32, except k == 6 (stored densely, kp = 6; a buffer of
+ *     s*8 slots is always large enough).  xyz1 (b,s,3), feat1 (b,s,c), xyz2 (b,n,3), feat2 (b,n,c),
+ *     idx (b,s,k).  a1 and a2 of one cost volume must be called with the same k.
  * a2: mlp_conv_xyz_1(geometry10), mlp2_convs, softmax over k, sum_k w*pix -> out (b,s,64).
  * b : second aggregate over the k<=4 frame-1 neighbours idx (b,s,k) of each frame-1 point:
  *     mlp_conv_xyz_2, mlp3_convs([enc | feat1[s] | first[idx]]), softmax, sum_k w*first[idx]. */

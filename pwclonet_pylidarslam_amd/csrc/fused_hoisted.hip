@@ -439,10 +439,11 @@ extern "C" void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const f
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a1_h: nsample_q=%d outside [1,32]", k);
   CVHArgs a{xyz1, u, xyz2, v, nullptr, idx, packed_w, pix, b, n, s, k};
-  const int kp = k > 16 ? 32 : (k > 8 ? 16 : 8);
+  const int kp = cv_pix_slots(k);
   constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4) + layer_floats(4, 4));
-  static bool a32 = false, a16 = false, a8 = false;
-  if (kp == 32) launch_h<16>(cv_a1_h_kernel<32, 1, 16>, a32, lds, tiles_h(b, s, 32, 1), a);
+  static bool a32 = false, a16 = false, a8 = false, a6 = false;
+  if (kp == 6) launch_h<16>(cv_a1_h_kernel<6, 1, 16>, a6, lds, tiles_h(b, s, 6, 1), a);
+  else if (kp == 32) launch_h<16>(cv_a1_h_kernel<32, 1, 16>, a32, lds, tiles_h(b, s, 32, 1), a);
   else if (kp == 16) launch_h<16>(cv_a1_h_kernel<16, 1, 16>, a16, lds, tiles_h(b, s, 16, 1), a);
   else launch_h<16>(cv_a1_h_kernel<8, 1, 16>, a8, lds, tiles_h(b, s, 8, 1), a);
   check_launch("cv_fused_a1_h");

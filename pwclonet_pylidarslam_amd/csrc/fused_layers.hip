@@ -313,6 +313,85 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
   }
 }
 
+// a2 for K == 6 with no padded slots (the refinement levels: nsample_q = 6 would waste a quarter of
+// the matrix work in 8-wide groups).  A wave tile = 8 consecutive queries = 48 pixels = 3 blocks.
+// Lane j of block p (h = j >> 3, i = j & 7):
+//   i <  6: query 2p + h, neighbour i          -- "main" segment, 6 lanes of an 8-lane half row:
+//           reduced with the group-of-8 DPP ops, lanes 6,7 contributing the neutral element;
+//   i >= 6: query 6 + h,  neighbour 2p + (i-6) -- "split" segment, lanes 6,7 / 14,15 of the three
+//           blocks: reduced in-lane across the blocks, then across the lane pair (one DPP step).
+// cv_a1 writes the per-pixel features densely as (B, S, 6, 64) for this kernel.
+template <int W>
+__global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
+  constexpr int P = 3;
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats(8, 8), W2 = layer_floats(8, 4);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, WX + W1 + W2);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int i = j & 7, h = j >> 3;
+  const bool split = i >= 6;
+  const int tiles_per_cloud = (a.S + 7) / 8;
+  const int ntiles = a.B * tiles_per_cloud;
+  for (int t = blockIdx.x * W + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * W) {
+    const int b = t / tiles_per_cloud;
+    const int s0 = (t - b * tiles_per_cloud) * 8;
+    f32x4 geo[1][P], cat[8][P];
+    int sq[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int q = s0 + (split ? 6 + h : 2 * p + h);
+      const int k = split ? 2 * p + (i - 6) : i;
+      const bool valid = q < a.S;
+      const int s = valid ? q : a.S - 1;
+      sq[p] = valid ? s : -1;
+      const int nbr = a.idx[((size_t)b * a.S + s) * 6 + k];
+      geo[0][p] = geometry_block(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
+      load_row_blocks<4>(&cat[4][p], P, a.pix + (((size_t)b * a.S + s) * 6 + k) * 64, g);
+    }
+    f32x4 enc[4][P];
+    mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int p = 0; p < P; ++p) cat[m][p] = enc[m][p];
+    f32x4 h1[8][P], h2[4][P];
+    mlp_layer<8, 8, P, true>(h1, cat, lds_w + WX, lane);
+    mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      f32x4 res[P];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // logits are post-ReLU (>= 0): 0 is neutral for the max, and every segment has 6 real entries
+        float ms = split ? fmaxf(fmaxf(h2[o][0][c], h2[o][1][c]), h2[o][2][c]) : 0.f;
+        ms = fmaxf(ms, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(ms))));
+        float e[P];
+        float ds = 0.f, ns = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float mm = group_max_nonneg<8>(split ? 0.f : h2[o][p][c]);
+          e[p] = expf(h2[o][p][c] - (split ? ms : mm));
+          ds += split ? e[p] : 0.f;
+          ns += split ? e[p] * cat[4 + o][p][c] : 0.f;
+        }
+        ds += __uint_as_float(dpp_u32<0xB1>(__float_as_uint(ds)));
+        ns += __uint_as_float(dpp_u32<0xB1>(__float_as_uint(ns)));
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float dm = group_sum<8>(split ? 0.f : e[p]);
+          const float nm = group_sum<8>(split ? 0.f : e[p] * cat[4 + o][p][c]);
+          res[p][c] = split ? ns / ds : nm / dm;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if ((i == 0 || (i == 6 && p == 0)) && sq[p] >= 0)
+          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = res[p];
+    }
+  }
+}
+
 // b: enc2 = mlp_conv_xyz_2(geo'); w = softmax_k(mlp3_convs([enc2 | centre feat | gathered first]));
 //    out = sum_k w * gathered first.  Candidates = the frame-1 points themselves (N == S).
 template <int CB, int KP, int P, int W>
@@ -584,7 +663,7 @@ extern "C" void cv_fused_a1_kernel_wrapper(int b, int n, int s, int k, int c, co
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a1: nsample_q=%d outside [1,32]", k);
   CVArgs a{xyz1, feat1, xyz2, feat2, idx, packed_w, pix, nullptr, b, n, s, k, fl_tuning("PWCLO_FL_STAGGER", 0)};
-  const int kp = k > 16 ? 32 : (k > 8 ? 16 : 8);
+  const int kp = cv_pix_slots(k);
 #define A1_CASE(C, KP)                                                                              \
   if (c == C && kp == KP) {                                                                         \
     static bool attr = false, attr1 = false;                                                        \
@@ -595,7 +674,7 @@ extern "C" void cv_fused_a1_kernel_wrapper(int b, int n, int s, int k, int c, co
     check_launch("cv_fused_a1");                                                                    \
     return;                                                                                         \
   }
-  A1_CASE(64, 32) A1_CASE(64, 8) A1_CASE(32, 8) A1_CASE(16, 8)
+  A1_CASE(64, 32) A1_CASE(64, 8) A1_CASE(32, 8) A1_CASE(16, 8) A1_CASE(64, 6) A1_CASE(32, 6) A1_CASE(16, 6)
 #undef A1_CASE
   set_error(PWCLO_EINVAL, "cv_fused_a1: no kernel for c=%d nsample_q=%d", c, k);
 }
@@ -607,11 +686,12 @@ extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const flo
   PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a2: nsample_q=%d outside [1,32]", k);
   CVArgs a{xyz1, nullptr, xyz2, nullptr, idx, packed_w, const_cast<float *>(pix), out, b, n, s, k,
            fl_tuning("PWCLO_FL_STAGGER", 0)};
-  const int kp = k > 16 ? 32 : (k > 8 ? 16 : 8);
+  const int kp = cv_pix_slots(k);
   constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(8, 8) + layer_floats(8, 4));
-  static bool attr32 = false, attr16 = false, attr8 = false, attr16w = false, attr8w = false;
+  static bool attr32 = false, attr16 = false, attr8 = false, attr16w = false, attr8w = false, attr6 = false;
   static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);
-  if (kp == 32) launch_persistent<8>(cv_a2_kernel<32, 2, 8>, attr32, lds, tiles_of(b, s, 32, 2), a);
+  if (kp == 6) launch_persistent<8>(cv_a2_dense6_kernel<8>, attr6, lds, (long long)b * ((s + 7) / 8), a);
+  else if (kp == 32) launch_persistent<8>(cv_a2_kernel<32, 2, 8>, attr32, lds, tiles_of(b, s, 32, 2), a);
   else if (kp == 16 && wide) launch_persistent<16>(cv_a2_kernel<16, 1, 16>, attr16w, lds, tiles_of(b, s, 16, 1), a);
   else if (kp == 16) launch_persistent<8>(cv_a2_kernel<16, 2, 8>, attr16, lds, tiles_of(b, s, 16, 2), a);
   else if (wide) launch_persistent<16>(cv_a2_kernel<8, 1, 16>, attr8w, lds, tiles_of(b, s, 8, 1), a);

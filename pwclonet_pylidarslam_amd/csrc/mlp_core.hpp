@@ -19,6 +19,8 @@
 // fp32 MFMA is bit-for-bit an fmaf chain in k order, so results differ from a CPU GEMM only by
 // summation order (parity bound 1e-5, tests/test_gpu_fused.py).
 #pragma once
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace pwclo {
@@ -165,7 +167,18 @@ __device__ __forceinline__ float group_max_nonneg(float v) {
 }
 
 // ---- pixel bookkeeping --------------------------------------------------------------------------
-// pixel index -> (query s, neighbour slot k); KP is a power of two.
+// Neighbour slots per query of the cost volume's per-pixel feature buffer (cv_a1 -> cv_a2): K
+// rounded up to 8 / 16 / 32, except K == 6 (the refinement levels), which is stored densely and
+// consumed by cv_a2_dense6_kernel.  PWCLO_DENSE6=0 restores the padded layout (A/B switch).
+// fused.py: cv_pix_slots mirrors this.
+static inline int cv_pix_slots(int k) {
+  static int dense6 = -1;
+  if (dense6 < 0) { const char *e = getenv("PWCLO_DENSE6"); dense6 = e ? atoi(e) : 1; }
+  if (k == 6 && dense6) return 6;
+  return k > 16 ? 32 : (k > 8 ? 16 : 8);
+}
+
+// pixel index -> (query s, neighbour slot k).
 template <int KP>
 struct PixelMap {
   int s, k;

@@ -249,7 +249,7 @@ class FusedCostVolume:
         kq, k = self.nsample_q, self.nsample
         if idx_q is None:
             idx_q = knn(kq, xyz2, xyz1)
-        kp = 32 if kq > 16 else (16 if kq > 8 else 8)
+        kp = cv_pix_slots(kq)
         pix = torch.empty((B, S * kp, 64), dtype=torch.float32, device=dev)
         c = self.c
         _lib.annotate(family="mlp", flops=2.0 * B * S * kq * self.macs_a1,
@@ -257,7 +257,8 @@ class FusedCostVolume:
         _lib.call("cv_fused_a1_kernel_wrapper", dev, B, N, S, kq, self.c, _p(xyz1), _p(feat1), _p(xyz2),
                   _p(feat2), _p(idx_q), _p(self.w_a1), _p(pix))
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel="cv_a2_kernel<%s>" % {32: "32, 2, 8", 16: "16, 1, 16", 8: "8, 1, 16"}[kp],
+        _lib.annotate(family="mlp", kernel={32: "cv_a2_kernel<32, 2, 8>", 16: "cv_a2_kernel<16, 1, 16>", 8: "cv_a2_kernel<8, 1, 16>",
+                                            6: "cv_a2_dense6_kernel<8>"}[kp],
                       flops=2.0 * B * S * kq * self.macs_a2,
                       bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
@@ -334,6 +335,14 @@ def run_linear_jobs(jobs):
                   pa([_p(j.packed) for j, _ in chunk]), pa([_p(r) for r in res]))
         outs.extend(res)
     return outs
+
+
+def cv_pix_slots(k):
+    """Neighbour slots per query of cv_a1's per-pixel buffer (csrc/mlp_core.hpp: cv_pix_slots)."""
+    import os
+    if k == 6 and os.environ.get("PWCLO_DENSE6", "1") != "0":
+        return 6
+    return 32 if k > 16 else (16 if k > 8 else 8)
 
 
 def kstep_major_map(n):
@@ -484,14 +493,15 @@ class FusedCostVolumeHoisted:
         kq, k, c = self.nsample_q, self.nsample, self.c
         if idx_q is None:
             idx_q = knn(kq, xyz2, xyz1)
-        kp = 32 if kq > 16 else (16 if kq > 8 else 8)
+        kp = cv_pix_slots(kq)
         pix = torch.empty((B, S * kp, 64), dtype=torch.float32, device=dev)
         _lib.annotate(family="mlp", flops=2.0 * B * S * kq * (self.macs_a1 - 2 * c * 128),
                       bytes=4.0 * B * (S * kq * (1 + 3 + 128 + 64) + S * (3 + 128)))
         _lib.call("cv_fused_a1_h_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(u), _p(xyz2), _p(v), _p(idx_q),
                   _p(self.w_a1), _p(pix))
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel="cv_a2_kernel<%s>" % {32: "32, 2, 8", 16: "16, 1, 16", 8: "8, 1, 16"}[kp],
+        _lib.annotate(family="mlp", kernel={32: "cv_a2_kernel<32, 2, 8>", 16: "cv_a2_kernel<16, 1, 16>", 8: "cv_a2_kernel<8, 1, 16>",
+                                            6: "cv_a2_dense6_kernel<8>"}[kp],
                       flops=2.0 * B * S * kq * self.macs_a2,
                       bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),

@@ -74,7 +74,9 @@ class PipelinedForward:
     def __init__(self, net, depth=2):
         # single-branch graphs: two multi-branch graphs in flight serialise on this runtime
         # (measured: 5.35 ms/step with branches vs 4.0 ms without, 2 in flight)
-        self.slots = [GraphedForward(net, branch=False) for _ in range(depth)]
+        import os
+        branch = os.environ.get("PWCLO_PIPE_BRANCH", "0") != "0"
+        self.slots = [GraphedForward(net, branch=branch) for _ in range(depth)]
         self.streams = None
         self.events = [None] * depth
         self._next = 0
