@@ -152,7 +152,7 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
       mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
     }
     mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
-    mlp_layer<B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
+    mlp_layer<B2, B3, P, false>(h3, h2, lds_w + W1 + W2, lane);   // its ReLU is applied after the pool
     constexpr int GROUP = KP < 16 ? KP : 16;
     constexpr int BPQ = KP > 16 ? KP / 16 : 1;
 #pragma unroll
@@ -163,10 +163,10 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
 #pragma unroll
         for (int e = 1; e < BPQ; ++e) {
           const f32x4 u = h3[o][p + e];
-          v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
+          v.x = max_bits(v.x, u.x); v.y = max_bits(v.y, u.y); v.z = max_bits(v.z, u.z); v.w = max_bits(v.w, u.w);
         }
-        v.x = group_max_nonneg<GROUP>(v.x); v.y = group_max_nonneg<GROUP>(v.y);
-        v.z = group_max_nonneg<GROUP>(v.z); v.w = group_max_nonneg<GROUP>(v.w);
+        v.x = relu_bits(group_max_nonneg<GROUP>(v.x)); v.y = relu_bits(group_max_nonneg<GROUP>(v.y));
+        v.z = relu_bits(group_max_nonneg<GROUP>(v.z)); v.w = relu_bits(group_max_nonneg<GROUP>(v.w));
         if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
           *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * C3 + 16 * o + 4 * g) = v;
       }
@@ -217,15 +217,15 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
     mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
-    mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    mlp_layer<B1, B2, P, false>(h2, h1, lds_w + W1, lane);        // its ReLU is applied after the pool
     constexpr int GROUP = KP < 16 ? KP : 16;
 #pragma unroll
     for (int o = 0; o < B2; ++o)
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         f32x4 v = h2[o][p];
-        v.x = group_max_nonneg<GROUP>(v.x); v.y = group_max_nonneg<GROUP>(v.y);
-        v.z = group_max_nonneg<GROUP>(v.z); v.w = group_max_nonneg<GROUP>(v.w);
+        v.x = relu_bits(group_max_nonneg<GROUP>(v.x)); v.y = relu_bits(group_max_nonneg<GROUP>(v.y));
+        v.z = relu_bits(group_max_nonneg<GROUP>(v.z)); v.w = relu_bits(group_max_nonneg<GROUP>(v.w));
         if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
           *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = v;
       }

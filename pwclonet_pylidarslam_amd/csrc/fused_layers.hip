@@ -128,17 +128,17 @@ __global__ __launch_bounds__(W * 64) void upconv_kernel(UpconvArgs a) {
     }
     f32x4 h1[B1][P], h2[B2][P];
     mlp_layer<NBI, B1, P, true>(h1, in, lds_w, lane);
-    mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    mlp_layer<B1, B2, P, false>(h2, h1, lds_w + W1, lane);        // its ReLU is applied after the pool
     constexpr int GROUP = KP < 16 ? KP : 16;
 #pragma unroll
     for (int o = 0; o < B2; ++o) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         f32x4 v = h2[o][p];
-        v.x = group_max_nonneg<GROUP>(v.x);
-        v.y = group_max_nonneg<GROUP>(v.y);
-        v.z = group_max_nonneg<GROUP>(v.z);
-        v.w = group_max_nonneg<GROUP>(v.w);
+        v.x = relu_bits(group_max_nonneg<GROUP>(v.x));
+        v.y = relu_bits(group_max_nonneg<GROUP>(v.y));
+        v.z = relu_bits(group_max_nonneg<GROUP>(v.z));
+        v.w = relu_bits(group_max_nonneg<GROUP>(v.w));
         if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
           *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = v;
       }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_kernel(SAArgs a) {
     f32x4 h1[B1][P], h2[B2][P], h3[B3][P];
     mlp_layer<NBI, B1, P, true>(h1, in, lds_w, lane);
     mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
-    mlp_layer<B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
+    mlp_layer<B2, B3, P, false>(h3, h2, lds_w + W1 + W2, lane);   // its ReLU is applied after the pool
 
     // max over the K neighbours (F.max_pool2d(kernel=[1,K]), :239-243), then one 16-byte store
     // per (query, lane group, output block)
@@ -90,12 +90,12 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_kernel(SAArgs a) {
 #pragma unroll
         for (int e = 1; e < BPQ; ++e) {
           const f32x4 u = h3[o][p + e];
-          v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
+          v.x = max_bits(v.x, u.x); v.y = max_bits(v.y, u.y); v.z = max_bits(v.z, u.z); v.w = max_bits(v.w, u.w);
         }
-        v.x = group_max_nonneg<GROUP>(v.x);
-        v.y = group_max_nonneg<GROUP>(v.y);
-        v.z = group_max_nonneg<GROUP>(v.z);
-        v.w = group_max_nonneg<GROUP>(v.w);
+        v.x = relu_bits(group_max_nonneg<GROUP>(v.x));
+        v.y = relu_bits(group_max_nonneg<GROUP>(v.y));
+        v.z = relu_bits(group_max_nonneg<GROUP>(v.z));
+        v.w = relu_bits(group_max_nonneg<GROUP>(v.w));
         if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
           *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * C3 + 16 * o + 4 * g) = v;
       }

@@ -53,6 +53,22 @@ __device__ __forceinline__ void stage_weights(float *lds, const float *__restric
   stage_batch<1>(dst, src, i, n4, step);
 }
 
+// ReLU as ONE integer max on the bit pattern (negative floats are negative ints; -0.0 -> +0.0).
+// fmaxf(x, 0.f) costs two VALU instructions (the compiler canonicalises x first), and on gfx950 the
+// fp32 MFMA does not co-issue with other vector instructions of the SIMD (measured:
+// SQ_VALU_MFMA_BUSY + SQ_ACTIVE_INST_VALU = SQ_BUSY, co-execution 0), so every VALU instruction in a
+// stack kernel is time taken from the matrix pipe.
+__device__ __forceinline__ float relu_bits(float x) {
+  const int b = __float_as_int(x);
+  return __int_as_float(b < 0 ? 0 : b);
+}
+// max of two floats through their bit patterns as signed ints: exact when at least one is >= +0;
+// when both are negative the result is still negative (all a following relu_bits needs).
+__device__ __forceinline__ float max_bits(float a, float b) {
+  const int x = __float_as_int(a), y = __float_as_int(b);
+  return __int_as_float(x > y ? x : y);
+}
+
 // One layer for P pixel blocks.  `w` points at the layer's packed weights in LDS.
 // The (output block o, input block m) operand tiles are walked as ONE flat sequence with the next
 // tile's ds_read_b128 issued before the current tile's 4*P MFMAs (register double buffer, 8 VGPRs),
@@ -88,7 +104,7 @@ __device__ __forceinline__ void mlp_layer_init(f32x4 (&out)[NBO][P], const f32x4
       for (int p = 0; p < P; ++p) {
         if (RELU) {
           f32x4 v = acc[p];
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
           out[o][p] = v;
         } else {
           out[o][p] = acc[p];
@@ -117,12 +133,13 @@ __device__ __forceinline__ void mlp_layer(f32x4 (&out)[NBO][P], const f32x4 (&in
 // for the per-pixel MFMAs.  Same mathematics, different fp32 summation order (parity bound 1e-5).
 
 // ---- start-up stagger ------------------------------------------------------------------------------
-// All waves of a workgroup start their first tile together, and because they share one matrix pipe
-// per SIMD they stay in phase: every tile's gather prologue (two dependent global loads) and
-// epilogue then run with the pipe idle (measured: 66-77 % SQ_VALU_MFMA_BUSY).  Delaying the j-th
-// wave of a SIMD by j wave-shares of MFMA time once, at kernel start, puts one wave's
-// prologue/epilogue under the other waves' MFMAs for the rest of the kernel.  Waves w, w+4, w+8,
-// ... share a SIMD (cyclic placement); purely a performance device -- no correctness dependence.
+// Experiment kept for reference (PWCLO_FL_STAGGER, default off, no measurable effect): delay the j-th
+// wave of a SIMD once at kernel start so that one wave's gather prologue / epilogue would sit under
+// the other waves' MFMAs.  The premise was wrong for fp32: SQ_VALU_MFMA_BUSY + SQ_ACTIVE_INST_VALU
+// add up to the busy time with zero co-execution in every stack kernel, i.e. the fp32 MFMA and the
+// other vector instructions of a SIMD execute one after the other however the waves are phased
+// (and software-prefetching the next tile's gathers did not help either).  What does help is
+// issuing fewer VALU instructions per MFMA (relu_bits, ReLU after the pool, k-step trimming).
 __device__ __forceinline__ void stagger_start(int wave, int mfma_per_tile, int enable) {
   const int j = wave >> 2;
   if (enable && j > 0) {
@@ -160,7 +177,9 @@ __device__ __forceinline__ float group_sum(float v) {
   return __uint_as_float(group_allreduce_u32<GROUP>(__float_as_uint(v), OpAddF32()));
 }
 
-// max for values that are >= +0 (post-ReLU) or the sentinel -inf (bit pattern 0xff800000 < 0).
+// max for values that are >= +0 (post-ReLU) or the sentinel -inf (bit pattern 0xff800000 < 0); for
+// raw pre-activation values the result is exact whenever the true max is >= +0 and negative
+// otherwise, so relu(max_k x_k) == relu_bits(group_max_nonneg(x)) (ReLU after the pool: 1/K of the work).
 template <int GROUP>
 __device__ __forceinline__ float group_max_nonneg(float v) {
   return __uint_as_float(group_allreduce_u32<GROUP>(__float_as_uint(v), OpMaxF32Bits()));

@@ -55,12 +55,15 @@ void run(const char *name) {
 }
 
 int main() {
+  run<1, 8, 4, 1, 16>("upconv_h 16->128->64");
+  run<1, 8, 4, 2, 8>("upconv_h 16->128->64");
+  run<1, 8, 4, 3, 8>("upconv_h 16->128->64");
   run<5, 8, 4, 2, 8>("upconv 80->128->64");
   run<5, 8, 4, 1, 16>("upconv 80->128->64");
   run<5, 8, 4, 4, 4>("upconv 80->128->64");
-  run<9, 8, 4, 2, 8>("144->128->64");
-  run<9, 8, 4, 1, 16>("144->128->64");
-  run<8, 8, 4, 2, 8>("128->128->64");
+  run<8, 8, 4, 1, 16>("128->128->64 (cv_a2)");
+  run<8, 8, 4, 2, 8>("128->128->64 (cv_a2)");
+  run<8, 8, 4, 3, 8>("128->128->64 (cv_a2)");
   run<8, 8, 4, 4, 4>("128->128->64");
   run<8, 8, 4, 4, 8>("128->128->64");
   return 0;
