@@ -6,6 +6,9 @@ hipcc cross-compiles without a GPU, so this runs in the build container; the res
 ``pwclonet_pylidarslam_amd/lib/libpwclo_hip.so`` travels to the GPU box with the tree (it is
 git-ignored, not gpurun-ignored).  ``-ffp-contract=off``: the parity contract is source-order
 IEEE fp32 for every distance / interpolation expression (SURVEY.md section 7 "Hard parts").
+``-fno-slp-vectorize``: the SLP pass packs neighbouring fp32 adds into ``v_pk_add_f32``, which
+blocks the DPP fusion of the K-neighbour reductions (2 ``v_mov_b32_dpp`` + 1 packed add instead
+of 2 ``v_add_f32_dpp``) and is no faster than two scalar adds on gfx950.
 """
 import concurrent.futures
 import os
@@ -18,7 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libpwclo_hip.so")
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 

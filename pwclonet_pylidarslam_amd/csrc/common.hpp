@@ -43,7 +43,7 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 // ---- DPP helpers (gfx9 encodings: quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140).
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 
 // Reduce over each row of 16 lanes (result in every lane of the row): xor-1, xor-2 inside quads,

@@ -339,10 +339,10 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
         for (int c = 0; c < 4; ++c) {
           const float xv = padded[p] ? NEG_INF : h2[o][p][c];
           const float mx = group_max_nonneg<GROUP>(xv);
-          const float ex = padded[p] ? 0.f : expf(xv - mx);
+          const float ex = padded[p] ? 0.f : exp_nonpos(xv - mx);
           const float den = group_sum<GROUP>(ex);
           const float num = group_sum<GROUP>(ex * val[o][p][c]);
-          res[c] = num / den;
+          res[c] = div_ge1(num, den);
         }
         if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
           *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = res;

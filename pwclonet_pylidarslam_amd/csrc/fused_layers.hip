@@ -65,13 +65,13 @@ __device__ __forceinline__ void softmax_weighted_sum(f32x4 (&res)[P], const f32x
       float den = 0.f, num = 0.f;
 #pragma unroll
       for (int e = 0; e < BPQ; ++e) {
-        const float ex = padded[p + e] ? 0.f : expf(xv[e] - mx);
+        const float ex = padded[p + e] ? 0.f : exp_nonpos(xv[e] - mx);
         den += ex;
         num += ex * val[p + e][c];
       }
       den = group_sum<GROUP>(den);
       num = group_sum<GROUP>(num);
-      const float r = num / den;
+      const float r = div_ge1(num, den);
 #pragma unroll
       for (int e = 0; e < BPQ; ++e) res[p + e][c] = r;
     }
@@ -364,14 +364,14 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         // logits are post-ReLU (>= 0): 0 is neutral for the max, and every segment has 6 real entries
-        float ms = split ? fmaxf(fmaxf(h2[o][0][c], h2[o][1][c]), h2[o][2][c]) : 0.f;
-        ms = fmaxf(ms, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(ms))));
+        float ms = split ? max_bits(max_bits(h2[o][0][c], h2[o][1][c]), h2[o][2][c]) : 0.f;
+        ms = max_bits(ms, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(ms))));
         float e[P];
         float ds = 0.f, ns = 0.f;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const float mm = group_max_nonneg<8>(split ? 0.f : h2[o][p][c]);
-          e[p] = expf(h2[o][p][c] - (split ? ms : mm));
+          e[p] = exp_nonpos(h2[o][p][c] - (split ? ms : mm));
           ds += split ? e[p] : 0.f;
           ns += split ? e[p] * cat[4 + o][p][c] : 0.f;
         }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
         for (int p = 0; p < P; ++p) {
           const float dm = group_sum<8>(split ? 0.f : e[p]);
           const float nm = group_sum<8>(split ? 0.f : e[p] * cat[4 + o][p][c]);
-          res[p][c] = split ? ns / ds : nm / dm;
+          res[p][c] = split ? div_ge1(ns, ds) : div_ge1(nm, dm);
         }
       }
 #pragma unroll

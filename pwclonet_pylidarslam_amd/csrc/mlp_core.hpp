@@ -76,6 +76,14 @@ __device__ __forceinline__ float max_bits(float a, float b) {
 // hoisting every later read as well (which spilled).
 // `init(o, p)` seeds the accumulator of output block o / pixel block p: the layer's bias, or --
 // for hoisted first layers -- the per-point partial products gathered from memory (see below).
+// Softmax pieces for the K-neighbour epilogues, priced in VALU instructions (see relu_bits):
+// exp of a non-positive argument as v_mul + v_exp_f32 (expf is a 12-instruction sequence; the
+// argument is x - max <= 0, the result feeds a ratio of sums, error ~1e-6 relative for |x| < 20),
+// and a quotient whose denominator is >= 1 (it contains exp(0)) as v_rcp_f32 + v_mul (IEEE division
+// is ~10 instructions).  Both stay inside the 1e-5 parity bound of the fused layers.
+__device__ __forceinline__ float exp_nonpos(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float div_ge1(float num, float den) { return num * __builtin_amdgcn_rcpf(den); }
+
 // KS < 4 runs only the first KS 4-channel k-steps of every input block: for a lone geometry block
 // whose channels 4*KS.. are zero padding (3 or 6 or 10 real inputs) the other MFMAs multiply zeros.
 template <int NBI, int NBO, int P, bool RELU, int KS = 4, typename Init>
