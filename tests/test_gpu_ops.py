@@ -80,6 +80,18 @@ def test_fps_kitti_shaped_batch32(cuda):
     assert torch.equal(out[:2], ref)
 
 
+def test_fps_batch16_ties_and_padding(cuda):
+    """A 16-cloud batch of lattice clouds (almost every arg-max is a tie) with zero padding in some
+    of them: every cloud independently follows the reference's tie rule."""
+    gen = torch.Generator().manual_seed(2024)
+    x = torch.randint(-6, 7, (16, 5000, 3), generator=gen).float()
+    x[3, :1000] = 0.0
+    x[8, 2500:] = 0.0
+    ref = O.furthest_point_sampling(x, 300)
+    out = E.furthest_point_sampling(g(x, cuda), 300).cpu()
+    assert torch.equal(out, ref)
+
+
 # ---------------------------------------------------------------- gather / group (+ grads)
 @pytest.mark.parametrize("b,c,n,m", [(2, 3, 8192, 2048), (3, 3, 256, 64), (2, 7, 100, 33), (1, 64, 1024, 1)])
 def test_gather_points(cuda, b, c, n, m):
