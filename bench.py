@@ -211,7 +211,7 @@ def main():
                     help="reference-shaped module graph on the HIP ops (torch conv/BN) instead of the fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=6)
+    ap.add_argument("--cpu-pairs", type=int, default=16)
     args = ap.parse_args()
 
     rank, local_rank, world = dist_util.env_world()
