@@ -250,6 +250,8 @@ def main():
                 pose, _ = net(x1, None, x2, None)
             return pose
 
+    if pipe is not None:
+        pipe.prepare(x1, x2)          # graph capture of every slot is set-up, not a warm-up step
     for _ in range(args.warmup):
         step()
 

@@ -95,6 +95,12 @@ class PipelinedForward:
         self.events[i] = ev
         return out, i
 
+    def prepare(self, xyz_f1, xyz_f2):
+        """Capture every slot's graph now (otherwise a slot is captured on its first use)."""
+        for _ in self.slots:
+            self(xyz_f1, xyz_f2)
+        self.wait_all()
+
     def wait(self, slot):
         if self.events[slot] is not None:
             self.events[slot].synchronize()
@@ -182,6 +188,11 @@ class StagedPipeline:
             sl["ev_r"].record(sr)
         self.last_log_dict = sl["log"]
         return sl["pose"], k
+
+    def prepare(self, xyz_f1, xyz_f2):
+        """Capture all slots now (done on first use otherwise)."""
+        if self._slots is None:
+            self._setup(xyz_f1, xyz_f2)
 
     def wait(self, slot):
         ev = self._slots[slot]["ev_r"] if self._slots else None
