@@ -154,6 +154,12 @@ void furthest_point_sampling_xyz_kernel_wrapper(int b, int n, int m, const float
  * -> out (2b,n,3) point-major, frame 1 first. */
 void ingest_pairs_kernel_wrapper(int b, int n, const float *xyz_f1, const float *xyz_f2, float *out);
 
+/* The same batch straight from the prediction module's inputs (slam/training/prediction_modules.py:
+ * 144-160: `pcd[:, :num_points, :3]` then permute): frame1/frame2 (b, n_total, c) point-major with
+ * c >= 3 floats per point; the first n points and first 3 channels of each -> out (2b, n, 3). */
+void ingest_frames_kernel_wrapper(int b, int n, int n_total, int c, const float *frame1,
+                                  const float *frame2, float *out);
+
 /* quat_warp_kernel_wrapper on point-major clouds: xyz, out (b,n,3). */
 void quat_warp_pm_kernel_wrapper(int b, int n, const float *xyz, const float *q, const float *t,
                                  float *out);

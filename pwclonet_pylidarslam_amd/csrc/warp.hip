@@ -58,9 +58,38 @@ __global__ __launch_bounds__(256) void ingest_pairs_kernel(int bsz, int n, const
   dst[2] = src[2 * n + j];
 }
 
+// Input adapter one level up (prediction_modules.py:144-160): two point-major frames (B, n_total, c),
+// c >= 3 floats per point, of which the first n points and the first 3 channels are used
+// (`pcd[:, :num_points, :3]`) -> the same (2B,n,3) batch.  Replaces slice + permute + contiguous in
+// the reference's adapter and the permute back in the fused forward.
+__global__ __launch_bounds__(256) void ingest_frames_kernel(int bsz, int n, int n_total, int c,
+                                                            const float *__restrict__ f1,
+                                                            const float *__restrict__ f2,
+                                                            float *__restrict__ out) {
+  const int b = blockIdx.y;               // 0 .. 2*bsz-1
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const float *src = (b < bsz ? f1 + (size_t)b * n_total * c : f2 + (size_t)(b - bsz) * n_total * c) + (size_t)j * c;
+  float *dst = out + ((size_t)b * n + j) * 3;
+  dst[0] = src[0];
+  dst[1] = src[1];
+  dst[2] = src[2];
+}
+
 }  // namespace pwclo
 
 using namespace pwclo;
+
+extern "C" void ingest_frames_kernel_wrapper(int b, int n, int n_total, int c, const float *frame1,
+                                             const float *frame2, float *out) {
+  if (b <= 0 || n <= 0) return;
+  PWCLO_REQUIRE(2 * b <= 65535, "ingest_frames: b=%d exceeds the grid limit", b);
+  PWCLO_REQUIRE(c >= 3 && n_total >= n, "ingest_frames: need c >= 3 and n_total >= n (c=%d n_total=%d n=%d)", c,
+                n_total, n);
+  hipLaunchKernelGGL(ingest_frames_kernel, dim3(ceil_div(n, 256), 2 * b), dim3(256), 0, current_stream(), b, n,
+                     n_total, c, frame1, frame2, out);
+  check_launch("ingest_frames");
+}
 
 extern "C" void ingest_pairs_kernel_wrapper(int b, int n, const float *xyz_f1, const float *xyz_f2,
                                             float *out) {

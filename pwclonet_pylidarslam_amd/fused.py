@@ -624,11 +624,25 @@ class FusedPWCLONet:
         Returns the state ``rest`` consumes.  (Split out so that a pipeline can run the sampling
         chains of successive batches back to back on one stream: graphed.StagedPipeline.)"""
         B, _, N0 = xyz_f1.shape
-        if br is None:
-            br = _Branches(xyz_f1.device, False)
         x = torch.empty((2 * B, N0, 3), dtype=torch.float32, device=xyz_f1.device)  # both frames, point-major
         _lib.call("ingest_pairs_kernel_wrapper", x.device, B, N0, _p(xyz_f1.contiguous()),
                   _p(xyz_f2.contiguous()), _p(x))
+        return self._sample_chain(B, x, br)
+
+    @torch.no_grad()
+    def sample_frames(self, frame1, frame2, num_points, br=None):
+        """Stage 1 from the prediction module's inputs: two (B, n_total, c>=3) point-major frames, of
+        which ``[:, :num_points, :3]`` is used (prediction_modules.py:144-160) -- one pass, no permutes."""
+        B, n_total, c = frame1.shape
+        assert frame2.shape == frame1.shape and c >= 3 and n_total >= num_points
+        x = torch.empty((2 * B, num_points, 3), dtype=torch.float32, device=frame1.device)
+        _lib.call("ingest_frames_kernel_wrapper", x.device, B, num_points, n_total, c, _p(frame1.contiguous()),
+                  _p(frame2.contiguous()), _p(x))
+        return self._sample_chain(B, x, br)
+
+    def _sample_chain(self, B, x, br):
+        if br is None:
+            br = _Branches(x.device, False)
         # The sampling chain of all four levels depends only on the input cloud: it runs ahead on its
         # own branch while the main branch does neighbour search + MLP level by level.
         samples, ready = [], []
@@ -684,3 +698,9 @@ class FusedPWCLONet:
         """xyz_f1, xyz_f2 (B,3,N) -> pose_params (B,4,7) [+ dict of point-major intermediates]."""
         br = _Branches(xyz_f1.device, self.branch and torch.cuda.is_current_stream_capturing())
         return self.rest(self.sample(xyz_f1, xyz_f2, br), return_intermediates)
+
+    @torch.no_grad()
+    def forward_frames(self, frame1, frame2, num_points, return_intermediates=False):
+        """The forward from two (B, n_total, c>=3) point-major frames (see ``sample_frames``)."""
+        br = _Branches(frame1.device, self.branch and torch.cuda.is_current_stream_capturing())
+        return self.rest(self.sample_frames(frame1, frame2, num_points, br), return_intermediates)

@@ -250,3 +250,30 @@ def test_fused_forward_is_bitwise_deterministic_and_graph_safe(cuda):
     _, lazy = net.prepare_fused()(x1, None, x2, None)      # fused path: same values, built on access
     torch.testing.assert_close(lazy["embedding_mask"], log["embedding_mask"], rtol=1e-4, atol=1e-6)
     assert torch.equal(lazy["point_cloud"], log["point_cloud"])
+
+
+def test_prediction_module_adapter_matches_forward(cuda):
+    """frames (B, n_total, 3) through the adapter == the reference-shaped call on
+    `frame[:, :num_points, :3]` permuted to (B,3,N): bitwise on the fused path (same kernels, the ingest
+    kernel only moves data), and the module route (no packed weights) is the same call."""
+    from pwclonet_pylidarslam_amd.prediction import PWCLONetPredictionModule
+    pc1, pc2, _, _ = synthetic.kitti_like_pair(43, 2304, 2)
+    f1 = torch.from_numpy(pc1[:, :, :3]).contiguous().to(cuda)        # (B, 2304, 3)
+    f2 = torch.from_numpy(pc2[:, :, :3]).contiguous().to(cuda)
+    mod = PWCLONetPredictionModule(dict(device=str(cuda), num_input_channels=3, sequence_len=2, num_points=2048,
+                                        nb_levels=4, scalar_last=False, posenet_config=dict(log_mode="device")))
+    params.fill_state_dict(mod.pwclonet.state_dict())
+    mod = mod.to(cuda).eval()
+    x1 = f1[:, :2048].permute(0, 2, 1).contiguous()
+    x2 = f2[:, :2048].permute(0, 2, 1).contiguous()
+    with torch.no_grad():
+        ref_module, _ = mod.pwclonet(x1, None, x2, None)
+        got_module, _ = mod([f1, f2])
+    assert torch.equal(got_module, ref_module)
+    mod.pwclonet.prepare_fused()
+    with torch.no_grad():
+        ref_fused, ref_log = mod.pwclonet(x1, None, x2, None)
+        got_fused, log = mod({"numpy_pc_0": f1, "numpy_pc_1": f2})
+    assert torch.equal(got_fused, ref_fused)
+    assert torch.equal(log["point_cloud"], ref_log["point_cloud"])
+    torch.testing.assert_close(got_fused, ref_module, rtol=0, atol=5e-5)

@@ -190,3 +190,28 @@ def test_two_rank_gloo_benchmark_plumbing(tmp_path):
     (r0, w0, lo0, hi0, s0, t0), (r1, w1, lo1, hi1, s1, t1) = rows
     assert (w0, w1) == ("2", "2") and (lo0, hi0, lo1, hi1) == ("0", "33", "33", "65")
     assert float(s0) == float(s1) == 2.0 and float(t0) == float(t1) == 65.0
+
+
+def test_prediction_module_adapter_contract():
+    """Input adapter of the prediction module (prediction_modules.py:130-154): dict keys numpy_pc_{i},
+    list of two frames, and the reference's two RuntimeErrors; state_dict keys carry the `pwclonet.` prefix."""
+    import pytest
+    import torch
+    from pwclonet_pylidarslam_amd.prediction import PWCLONetPredictionModule
+    mod = PWCLONetPredictionModule(dict(device="cpu", num_input_channels=3, sequence_len=2, num_points=64,
+                                        nb_levels=4, scalar_last=False, posenet_config={}))
+    a, b = torch.zeros(2, 80, 3), torch.ones(2, 80, 3)
+    f = mod._frames({"numpy_pc_0": a, "numpy_pc_1": b, "other": 1})
+    assert f[0] is a and f[1] is b
+    f = mod._frames([a, b])
+    assert f[0] is a and f[1] is b
+    with pytest.raises(RuntimeError, match="key `numpy_pc_1` not found"):
+        mod._frames({"numpy_pc_0": a})
+    with pytest.raises(RuntimeError, match="either dict or list"):
+        mod._frames((a, b))
+    with pytest.raises(AssertionError):
+        PWCLONetPredictionModule(dict(device="cpu", sequence_len=3))
+    keys = list(mod.state_dict().keys())
+    assert len(keys) == 510 and all(k.startswith("pwclonet.") for k in keys)
+    with pytest.raises(RuntimeError, match="CPU not supported"):       # no CPU path in the product
+        mod.eval()([a, b])
