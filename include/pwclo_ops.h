@@ -63,8 +63,10 @@ void gather_points_grad_kernel_wrapper(int b, int c, int n, int npoints, const f
 
 /* sampling.cpp:11-13 / sampling_gpu.cu:175-229.  Iterative furthest point sampling.
  * dataset (b,n,3) f32; temp (b,n) f32 scratch pre-filled with 1e10 by the caller
- * (sampling.cpp:74-76; this implementation keeps the running distances in registers and only
- * requires temp to be a valid (b,n) buffer or NULL); idxs (b,m) i32.  Index 0 is always the
+ * (sampling.cpp:74-76).  This implementation keeps the running distances in registers: temp may be
+ * NULL for n <= 24576; for larger clouds it must be the (b,n) buffer (8-byte aligned) and is used --
+ * and overwritten -- as the exchange workspace of the cooperative multi-workgroup sampler (or, with
+ * PWCLO_FPS_COOP=0, as the running distances of the streaming fallback).  idxs (b,m) i32.  Index 0 is always the
  * first sample; points with x*x+y*y+z*z <= 1e-3 are never selected; ties are resolved exactly
  * as the reference's block-of-opt_n_threads(n) tree reduction does ("FPS tie rule"). */
 void furthest_point_sampling_kernel_wrapper(int b, int n, int m, const float *dataset,

@@ -16,6 +16,7 @@
 // maximises the distance and, among equal distances, minimises pri.  A thread whose points are
 // all skipped (|p|^2 <= 1e-3) or out of range contributes nothing; if no thread has a
 // candidate the result is index 0, as in the reference (best = -1, besti = 0 everywhere).
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -213,6 +214,131 @@ __global__ __launch_bounds__(T) void fps_stream_kernel(int n, int m, int bs, int
   }
 }
 
+// Clouds too large for one workgroup's registers (n > 24576, e.g. raw 120k-point KITTI-360 frames
+// sampled to 8192): G workgroups of 1024 threads share one cloud, every point still lives in a VGPR
+// for the whole call, and each iteration ends in one cross-workgroup exchange through global memory:
+//   workgroup-local arg-max (as fps_reg_kernel) -> its leader posts the key with a device-scope
+//   atomic max into a rotating global slot, arrives on a per-cloud counter (release), spins until all
+//   G have arrived (acquire), reads the winning key and broadcasts it through LDS.
+// Virtual thread id vtid = g*1024 + tid over T_total = G*1024 >= bs threads reproduces exactly the
+// E == 0 indexing of fps_reg_kernel (thread owns residue vtid mod bs, points k = vtid + T_total*i),
+// hence the same tie rule.  All G*clouds workgroups of a launch must be resident together (the host
+// launches at most 224 at a time); every spin is bounded, a timeout raises the error word and ends
+// the kernel.  Workspace (the reference's `temp` scratch): 8 u64 per cloud, zeroed by fps_coop_init.
+constexpr int COOP_T = 1024;
+constexpr int COOP_WS_WORDS = 8;     // u64 per cloud: [0..2] rotating key slots, [3] arrivals, [4] error
+
+__global__ void fps_coop_init_kernel(unsigned long long *ws, int nwords) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nwords) ws[i] = 0ull;
+}
+
+template <int I>
+__global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, int log2bs, int G,
+                                                          const float *__restrict__ dataset,
+                                                          unsigned long long *__restrict__ ws,
+                                                          int *__restrict__ idxs,
+                                                          float *__restrict__ new_xyz) {
+  __shared__ unsigned long long slots[3];
+  __shared__ unsigned long long bcast;
+  const int g = blockIdx.x, cloud = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int vtid = g * COOP_T + tid, ttotal = G * COOP_T;
+  const float *pts = dataset + (size_t)cloud * n * 3;
+  int *out = idxs + (size_t)cloud * m;
+  float *oxyz = new_xyz ? new_xyz + (size_t)cloud * m * 3 : nullptr;
+  unsigned long long *gslot = ws + (size_t)cloud * COOP_WS_WORDS;
+  unsigned long long *arrive = gslot + 3, *errw = gslot + 4;
+
+  float x[I], y[I], z[I];
+  int td[I];
+#pragma unroll
+  for (int i = 0; i < I; ++i) {
+    const int k = vtid + ttotal * i;
+    float px = 0.f, py = 0.f, pz = 0.f, t0 = -1.0f;
+    if (k < n) {
+      px = pts[(size_t)k * 3 + 0]; py = pts[(size_t)k * 3 + 1]; pz = pts[(size_t)k * 3 + 2];
+      const float mag = (px * px) + (py * py) + (pz * pz);
+      if (!((double)mag <= 1e-3)) t0 = 1e10f;
+    }
+    x[i] = px; y[i] = py; z[i] = pz; td[i] = __float_as_int(t0);
+  }
+  const unsigned pri_base = (fps_bitrev((unsigned)(vtid & (bs - 1)), log2bs) << PRI_SHIFT) | (unsigned)(vtid / bs);
+  const unsigned qstep = (unsigned)(ttotal / bs);
+  if (tid == 0) {
+    slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull;
+    if (g == 0) out[0] = 0;
+  }
+  __syncthreads();
+
+  int old = 0;
+  bool failed = false;
+  for (int it = 1; it < m && !failed; ++it) {
+    const float x1 = pts[(size_t)old * 3 + 0], y1 = pts[(size_t)old * 3 + 1], z1 = pts[(size_t)old * 3 + 2];
+    if (oxyz && g == 0 && tid == 0) {
+      oxyz[(it - 1) * 3 + 0] = x1; oxyz[(it - 1) * 3 + 1] = y1; oxyz[(it - 1) * 3 + 2] = z1;
+    }
+    int best = __float_as_int(-1.0f), bestj = 0;
+#pragma unroll
+    for (int j = 0; j < I; ++j) {
+      const float dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1;
+      const float d = dx * dx + dy * dy + dz * dz;
+      const int d2 = min(__float_as_int(d), td[j]);
+      td[j] = d2;
+      const bool better = d2 > best;
+      bestj = better ? j : bestj;
+      best = better ? d2 : best;
+    }
+    const unsigned mine = best < 0 ? 0u : (unsigned)best + 1u;
+    const unsigned wmax = wave_reduce_u32(mine, OpMaxU32());
+    const unsigned mypri = pri_base + qstep * (unsigned)bestj;
+    const unsigned cand = (mine == wmax && mine != 0u) ? mypri : 0xFFFFFFFFu;
+    const unsigned wpri = wave_reduce_u32(cand, OpMinU32());
+    const unsigned long long key =
+        wmax == 0u ? 0ull : (((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wpri));
+    unsigned long long *slot = slots + (it % 3);
+    if (lane == 0) atomicMax(slot, key);
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned long long lkey = *slot;
+      slots[(it + 2) % 3] = 0ull;
+      unsigned long long *gs = gslot + (it % 3);
+      if (lkey != 0ull) __hip_atomic_fetch_max(gs, lkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(arrive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long target = (unsigned long long)G * (unsigned long long)it;
+      unsigned long long gkey = ~0ull;   // ~0 = "timed out"
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) {
+          gkey = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        if (__hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (gkey == ~0ull) __hip_atomic_store(errw, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // slot (it+2)%3 was last read at iteration it-1, i.e. before every leader's arrival above
+      else if (g == 0) __hip_atomic_store(gslot + ((it + 2) % 3), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bcast = gkey;
+    }
+    __syncthreads();
+    const unsigned long long kmax = bcast;
+    if (kmax == ~0ull) {
+      failed = true;
+    } else if (kmax == 0ull) {
+      old = 0;
+    } else {
+      const unsigned p = 0xFFFFFFFFu - (unsigned)(kmax & 0xFFFFFFFFull);
+      old = (int)fps_bitrev(p >> PRI_SHIFT, log2bs) + bs * (int)(p & ((1u << PRI_SHIFT) - 1u));
+    }
+    if (g == 0 && tid == 0 && !failed) out[it] = old;
+  }
+  if (oxyz && g == 0 && tid == 0 && !failed) {
+    oxyz[(m - 1) * 3 + 0] = pts[(size_t)old * 3 + 0];
+    oxyz[(m - 1) * 3 + 1] = pts[(size_t)old * 3 + 1];
+    oxyz[(m - 1) * 3 + 2] = pts[(size_t)old * 3 + 2];
+  }
+}
+
 template <int T, int E, int I>
 static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float *dataset, int *idxs,
                            float *new_xyz) {
@@ -321,6 +447,25 @@ static void fps_dispatch(int b, int n, int m, const float *dataset, float *temp,
   }
   PWCLO_REQUIRE(temp != nullptr,
                 "furthest_point_sampling: n=%d needs the (b,n) temp buffer pre-filled with 1e10", n);
+  static int coop = -1;
+  if (coop < 0) { const char *e = getenv("PWCLO_FPS_COOP"); coop = e ? atoi(e) : 1; }
+  const int G = ceil_div(n, COOP_T * 16);                // workgroups per cloud, <= 16 points per thread
+  if (coop && G <= 32 && (reinterpret_cast<uintptr_t>(temp) & 7) == 0 && (size_t)b * COOP_WS_WORDS * 2 <= (size_t)b * n) {
+    // cooperative multi-workgroup sampler; `temp` doubles as its (re-zeroed) exchange workspace
+    unsigned long long *ws = reinterpret_cast<unsigned long long *>(temp);
+    hipStream_t st = current_stream();
+    hipLaunchKernelGGL(fps_coop_init_kernel, dim3(ceil_div(b * COOP_WS_WORDS, 256)), dim3(256), 0, st, ws,
+                       b * COOP_WS_WORDS);
+    const int per_launch = 224 / G;                      // all workgroups of a launch must be co-resident
+    for (int c0 = 0; c0 < b; c0 += per_launch) {
+      const int nb = min(per_launch, b - c0);
+      hipLaunchKernelGGL((fps_coop_kernel<16>), dim3(G, nb), dim3(COOP_T), 0, st, n, m, bs, log2bs, G,
+                         dataset + (size_t)c0 * n * 3, ws + (size_t)c0 * COOP_WS_WORDS, idxs + (size_t)c0 * m,
+                         new_xyz ? new_xyz + (size_t)c0 * m * 3 : nullptr);
+    }
+    check_launch("furthest_point_sampling(coop)");
+    return;
+  }
   hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, current_stream(), n, m, bs,
                      log2bs, dataset, temp, idxs, new_xyz);
   check_launch("furthest_point_sampling(stream)");

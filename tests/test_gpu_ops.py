@@ -92,6 +92,21 @@ def test_fps_batch16_ties_and_padding(cuda):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("b,n,m,lattice", [(3, 30000, 150, False), (2, 40001, 120, True), (9, 25000, 40, False)])
+def test_fps_large_cloud_cooperative(cuda, b, n, m, lattice):
+    """n > 24576: several workgroups share a cloud and exchange their arg-max through global memory
+    (csrc/sampling.hip: fps_coop_kernel); same indices as the oracle, ties and zero padding included."""
+    gen = torch.Generator().manual_seed(n + m)
+    if lattice:
+        x = torch.randint(-9, 10, (b, n, 3), generator=gen).float()
+    else:
+        x = (torch.rand(b, n, 3, generator=gen) * 2 - 1) * 40
+    x[0, 100:5000] = 0.0
+    ref = O.furthest_point_sampling(x, m)
+    out = E.furthest_point_sampling(g(x, cuda), m).cpu()
+    assert torch.equal(out, ref)
+
+
 # ---------------------------------------------------------------- gather / group (+ grads)
 @pytest.mark.parametrize("b,c,n,m", [(2, 3, 8192, 2048), (3, 3, 256, 64), (2, 7, 100, 33), (1, 64, 1024, 1)])
 def test_gather_points(cuda, b, c, n, m):
