@@ -72,6 +72,39 @@ def _install_stubs():
         sys.modules["pyquaternion"] = m
 
 
+def _install_hydra_stubs():
+    """``slam/training/loss_modules.py:8-11`` needs ``hydra.conf.{dataclass,MISSING,field}`` and a
+    ``ConfigStore`` to register its config dataclasses with; neither is used by the loss arithmetic."""
+    import dataclasses
+    if "hydra" in sys.modules:
+        return
+    h, hc = types.ModuleType("hydra"), types.ModuleType("hydra.conf")
+    hcore, hcs = types.ModuleType("hydra.core"), types.ModuleType("hydra.core.config_store")
+    hc.dataclass, hc.MISSING, hc.field = dataclasses.dataclass, "???", dataclasses.field
+
+    class ConfigStore:
+        _inst = None
+
+        @classmethod
+        def instance(cls):
+            cls._inst = cls._inst or cls()
+            return cls._inst
+
+        def store(self, *a, **k):
+            pass
+
+    hcs.ConfigStore = ConfigStore
+    sys.modules.update({"hydra": h, "hydra.conf": hc, "hydra.core": hcore, "hydra.core.config_store": hcs})
+
+
+def load_loss():
+    """The reference's ``_PWCLONetLossModule`` / ``ExponentialWeights`` (loss_modules.py:147-545)."""
+    load()
+    _install_hydra_stubs()
+    import importlib
+    return importlib.import_module("slam.training.loss_modules")
+
+
 _loaded = None
 
 
