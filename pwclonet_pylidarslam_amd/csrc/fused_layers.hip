@@ -455,6 +455,8 @@ __global__ __launch_bounds__(64 * MP_PARTS) void masked_pool_kernel(int n, const
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6, b = blockIdx.x;
   const float *e = emb + (size_t)b * n * 64, *m = mask + (size_t)b * n * 64;
   float mx = -INFINITY;
+  // one coalesced 256-byte row per wave and trip: unrolled so that 8 loads are in flight per thread
+#pragma unroll 8
   for (int i = part; i < n; i += MP_PARTS) mx = fmaxf(mx, m[(size_t)i * 64 + c]);
   red[part][c] = mx;
   __syncthreads();
@@ -463,6 +465,7 @@ __global__ __launch_bounds__(64 * MP_PARTS) void masked_pool_kernel(int n, const
   for (int q = 1; q < MP_PARTS; ++q) mx = fmaxf(mx, red[q][c]);
   __syncthreads();
   float den = 0.f, num = 0.f;
+#pragma unroll 8
   for (int i = part; i < n; i += MP_PARTS) {
     const float ex = expf(m[(size_t)i * 64 + c] - mx);
     den += ex;
@@ -507,35 +510,48 @@ __device__ __forceinline__ void quat_mul(const float *a, const float *b, float *
 }
 
 __global__ __launch_bounds__(64 * MP_PARTS) void pose_head_kernel(PoseHeadArgs a) {
-  __shared__ float red[MP_PARTS][64];
-  __shared__ float red2[MP_PARTS][64];
+  // Pooling layout: a lane owns 4 channels (16-byte loads) of every 4th point of its wave's slice, so a
+  // wave-load covers 4 whole 256-byte rows; 64 (wave, point-slot) partials per channel meet in LDS.
+  __shared__ float red[4 * MP_PARTS][64];
+  __shared__ float red2[4 * MP_PARTS][64];
+  __shared__ float chmax[64];
   __shared__ float pooled[64];
   __shared__ float big[256];
   __shared__ float qt[8];
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6, b = blockIdx.x, n = a.n;
-  const float *e = a.emb + (size_t)b * n * 64, *m = a.mask + (size_t)b * n * 64;
-  float mx = -INFINITY;
-  for (int i = part; i < n; i += MP_PARTS) mx = fmaxf(mx, m[(size_t)i * 64 + c]);
-  red[part][c] = mx;
-  __syncthreads();
-  mx = red[0][c];
-#pragma unroll
-  for (int q = 1; q < MP_PARTS; ++q) mx = fmaxf(mx, red[q][c]);
-  __syncthreads();
-  float den = 0.f, num = 0.f;
-  for (int i = part; i < n; i += MP_PARTS) {
-    const float ex = expf(m[(size_t)i * 64 + c] - mx);
-    den += ex;
-    num += ex * e[(size_t)i * 64 + c];
+  const int c4 = 4 * (c & 15), sub = c >> 4, slot = 4 * part + sub;
+  const float *e = a.emb + (size_t)b * n * 64 + c4, *m = a.mask + (size_t)b * n * 64 + c4;
+  f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 4
+  for (int i = slot; i < n; i += 4 * MP_PARTS) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(m + (size_t)i * 64);
+    mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
   }
-  red[part][c] = den;
-  red2[part][c] = num;
+  *reinterpret_cast<f32x4 *>(&red[slot][c4]) = mx;
   __syncthreads();
   if (part == 0) {
-    float d = 0.f, s = 0.f;
-#pragma unroll
-    for (int q = 0; q < MP_PARTS; ++q) { d += red[q][c]; s += red2[q][c]; }
-    pooled[c] = s / d;
+    float v = red[0][c];
+    for (int q = 1; q < 4 * MP_PARTS; ++q) v = fmaxf(v, red[q][c]);
+    chmax[c] = v;
+  }
+  __syncthreads();
+  const f32x4 cm = *reinterpret_cast<const f32x4 *>(&chmax[c4]);
+  f32x4 den = {0.f, 0.f, 0.f, 0.f}, num = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int i = slot; i < n; i += 4 * MP_PARTS) {
+    const f32x4 mv = *reinterpret_cast<const f32x4 *>(m + (size_t)i * 64);
+    const f32x4 ev = *reinterpret_cast<const f32x4 *>(e + (size_t)i * 64);
+    const float e0 = expf(mv.x - cm.x), e1 = expf(mv.y - cm.y), e2 = expf(mv.z - cm.z), e3 = expf(mv.w - cm.w);
+    den.x += e0; den.y += e1; den.z += e2; den.w += e3;
+    num.x += e0 * ev.x; num.y += e1 * ev.y; num.z += e2 * ev.z; num.w += e3 * ev.w;
+  }
+  *reinterpret_cast<f32x4 *>(&red[slot][c4]) = den;
+  *reinterpret_cast<f32x4 *>(&red2[slot][c4]) = num;
+  __syncthreads();
+  if (part == 0) {
+    float d = 0.f, s_ = 0.f;
+    for (int q = 0; q < 4 * MP_PARTS; ++q) { d += red[q][c]; s_ += red2[q][c]; }
+    pooled[c] = s_ / d;
   }
   __syncthreads();
   if (threadIdx.x < 256) {                       // conv1d_q_t: 64 -> 256
@@ -633,11 +649,16 @@ extern "C" void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int
   PointwiseArgs a{{src0, src1, src2}, packed_w, out, b, s, fl_tuning("PWCLO_FL_STAGGER", 0)};
 #define PW_CASE(C0, C1, C2, A1, A2)                                                                 \
   if (c0 == C0 && c1 == C1 && c2 == C2 && w1 == A1 && w2 == A2) {                                   \
-    static bool attr = false, attr1 = false;                                                        \
+    static bool attr = false, attr1 = false, attr4 = false;                                         \
     static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);                                          \
     constexpr int NBI = (C0 + C1 + C2) / 16;                                                        \
     constexpr int lds = 4 * (layer_floats(NBI, A1 / 16) + (A2 > 0 ? layer_floats(A1 / 16, A2 / 16) : 0)); \
-    if (wide) launch_persistent<16>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 16>, \
+    /* few tiles (coarse levels): 4-wave workgroups spread them over 4x more CUs; a 16-wave        \
+       workgroup would run 4 tiles back to back on each SIMD while most of the chip idles */        \
+    if (wide && tiles_of(b, s, 1, 1) <= 2048)                                                       \
+      launch_persistent<4>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 4>,      \
+                           attr4, lds, tiles_of(b, s, 1, 1), a);                                    \
+    else if (wide) launch_persistent<16>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 16>, \
                                     attr1, lds, tiles_of(b, s, 1, 1), a);                           \
     else launch_persistent<8>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 2, 8>, attr, lds, \
                               tiles_of(b, s, 1, 2), a);                                             \
