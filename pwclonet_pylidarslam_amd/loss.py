@@ -97,6 +97,11 @@ class PWCLONetLossModule(nn.Module):
         loss = 1.6 * level_loss[3] + 0.8 * level_loss[2] + 0.4 * level_loss[1] + 0.2 * level_loss[0]
         log["loss"] = loss
         if self.with_exp_weights and self.exp_weighting is not None:
-            log["s_param_trans"] = self.exp_weighting.s_param[0].detach().cpu()
-            log["s_param_rot"] = self.exp_weighting.s_param[1].detach().cpu()
+            sp = self.exp_weighting.s_param.detach()
+            # the reference copies these two to the host (loss_modules.py:541-542); a device-to-host copy
+            # cannot be captured into a hipGraph, so they stay on the device while a capture is running
+            if not (sp.is_cuda and torch.cuda.is_current_stream_capturing()):
+                sp = sp.cpu()
+            log["s_param_trans"] = sp[0]
+            log["s_param_rot"] = sp[1]
         return loss, log

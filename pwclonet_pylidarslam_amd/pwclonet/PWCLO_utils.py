@@ -33,8 +33,10 @@ def mul_point_q(points, q, scalar_last: bool = False):
 def inv_q(q, device=None, scalar_last: bool = False):
     """conj(q) / (|q|^2 + 1e-10); q (B,4)."""
     q2 = torch.sum(q * q, dim=-1, keepdim=True) + 1e-10
-    sign = torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=q.dtype, device=q.device)
-    return (q * sign) / q2
+    # conj(q): same values as the reference's `q * [1,-1,-1,-1]` (PWCLO_utils.py:36) without building a
+    # device tensor from host data (a host->device copy cannot be captured into a hipGraph)
+    conj = torch.cat((q[..., :1], -q[..., 1:]), dim=-1)
+    return conj / q2
 
 
 def warp(xyz, q, t, device=None, scalar_last: bool = False):
