@@ -53,6 +53,9 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
                                                     int *__restrict__ idxs,
                                                     float *__restrict__ new_xyz) {
   constexpr int PPT = I << E;
+  // a sampler wave is one link of a long dependent chain: whenever it can issue, it should, ahead of
+  // the throughput kernels of other in-flight batches that may share its SIMD
+  __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [3] rotating
   float4 *table = reinterpret_cast<float4 *>(smem + FPS_SLOT_BYTES);         // [n] when LDS_TABLE
