@@ -152,6 +152,19 @@ void sa_fused_kernel_wrapper(int b, int n, int s, int k, int c_feat, int c1, int
 void furthest_point_sampling_xyz_kernel_wrapper(int b, int n, int m, const float *dataset,
                                                 float *temp, int *idxs, float *new_xyz);
 
+/* The same for a CHAIN of samplers (the pyramid: each level samples the previous level's samples).
+ * Sampling a cloud that is itself an FPS sample list, in sampling order, returns its prefix
+ * 0..m-1 whenever every arg-max of the producing call was unique; only exact distance ties, which
+ * the two calls break by different index priorities, can change the sequence (csrc/sampling.hip).
+ *   tie_out  (b) i32 or NULL: set to 1 for clouds in which one of the first tie_iters arg-max
+ *            decisions of THIS call was not unique (or had no candidate), else 0;
+ *   prefix_in (b) i32 or NULL: flags written by the call that produced `dataset`; clouds whose flag
+ *            is 0 get idx = 0..m-1 and their first m rows directly (m must be <= the tie_iters that call
+ *            was given), all others run the full algorithm.  Outputs are identical either way. */
+void furthest_point_sampling_chain_kernel_wrapper(int b, int n, int m, const float *dataset, float *temp,
+                                                  int *idxs, float *new_xyz, int *tie_out, int tie_iters,
+                                                  const int *prefix_in);
+
 /* Input adapter (pwclo_net.py:125-126 and the siamese batching): xyz_f1, xyz_f2 (b,3,n) channel-major
  * -> out (2b,n,3) point-major, frame 1 first. */
 void ingest_pairs_kernel_wrapper(int b, int n, const float *xyz_f1, const float *xyz_f2, float *out);

@@ -19,6 +19,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace pwclo {
@@ -47,17 +49,38 @@ __device__ __forceinline__ unsigned fps_bitrev(unsigned v, int bits) {
 // Cross-wave: lane 0 of each wave does ONE ds_max_u64 on a rotating LDS slot, one barrier, one
 // broadcast read.  Slot (it-1)%3 is cleared right after barrier `it` (every wave has read it
 // before arriving there, nobody adds to it before barrier it+1).
+//
+// Sampling chains.  When a cloud is the sample list of a previous FPS call, in sampling order (the
+// pyramid: level l samples level l-1's samples), its own FPS is a PREFIX of that list as long as
+// every arg-max of the previous call was unique: sample i+1 maximised the distance to samples 0..i
+// over the whole parent cloud, so it also maximises it over the subset, and the distances are the
+// same fp32 expressions on the same coordinates.  Only a tie -- two points at exactly the same
+// maximal distance, which the two calls would break by different index-based priorities -- can make
+// the sequences differ.  `tie_out`/`tie_iters`: this call records per cloud whether any of its first
+// tie_iters arg-max decisions was not unique (or had no candidate).  `prefix_in`: a later call on this
+// call's samples returns idx = 0..m-1 and the first m rows directly when the flag is clear, and runs
+// the full algorithm otherwise.  Results are identical to always running the full algorithm.
 template <int T, int E, int I, bool LDS_TABLE>
 __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int log2bs,
                                                     const float *__restrict__ dataset,
                                                     int *__restrict__ idxs,
-                                                    float *__restrict__ new_xyz) {
+                                                    float *__restrict__ new_xyz,
+                                                    int *__restrict__ tie_out, int tie_iters,
+                                                    const int *__restrict__ prefix_in) {
   constexpr int PPT = I << E;
+  if (prefix_in != nullptr && prefix_in[blockIdx.x] == 0) {       // workgroup-uniform
+    const float *src = dataset + (size_t)blockIdx.x * n * 3;
+    for (int i = threadIdx.x; i < m; i += T) idxs[(size_t)blockIdx.x * m + i] = i;
+    if (new_xyz)
+      for (int i = threadIdx.x; i < 3 * m; i += T) new_xyz[(size_t)blockIdx.x * m * 3 + i] = src[i];
+    return;
+  }
   // a sampler wave is one link of a long dependent chain: whenever it can issue, it should, ahead of
   // the throughput kernels of other in-flight batches that may share its SIMD
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [3] rotating
+  int *tieflag = reinterpret_cast<int *>(smem + 32);                         // inside the slot header
   float4 *table = reinterpret_cast<float4 *>(smem + FPS_SLOT_BYTES);         // [n] when LDS_TABLE
 
   const int tid = threadIdx.x;
@@ -93,11 +116,16 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
   if (tid == 0) {
     out[0] = 0;
     slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull;
+    *tieflag = 0;
   }
   __syncthreads();
 
   int old = 0;
-  for (int it = 1; it < m; ++it) {
+  // One iteration; TRACK additionally records whether the arg-max was unique.  Two instantiations run
+  // back to back (iterations < tie_iters, then the rest) rather than one loop with a branch inside:
+  // merging the two variants' register arrays at a join cost 50 VGPRs and a third of the speed.
+  auto iteration = [&](auto track_tag, int it) {
+    constexpr bool TRACK = decltype(track_tag)::value;
     float x1, y1, z1;
     if (LDS_TABLE) {
       const float4 p = table[old];
@@ -109,6 +137,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
       oxyz[(it - 1) * 3 + 0] = x1; oxyz[(it - 1) * 3 + 1] = y1; oxyz[(it - 1) * 3 + 2] = z1;
     }
     int best = __float_as_int(-1.0f);
+    int best2 = __float_as_int(-1.0f);   // TRACK: the lane's second-largest value (2 more integer ops per point)
     int bestj = 0;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -116,25 +145,37 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
       const float d = dx * dx + dy * dy + dz * dz;  // -ffp-contract=off: (a+b)+c, no FMA
       const int d2 = min(__float_as_int(d), td[j]); // == fminf for d >= +0, td >= +0 or td == -1.0f
       td[j] = d2;
+      if (TRACK) best2 = max(best2, min(d2, best));
       const bool better = d2 > best;
       bestj = better ? j : bestj;
       best = better ? d2 : best;
     }
+    const bool lane_tie = TRACK && best >= 0 && best2 == best;
     // 0 = no candidate; otherwise bits+1 so that a legitimate distance of +0.0 stays distinct
     const unsigned mine = best < 0 ? 0u : (unsigned)best + 1u;
     const unsigned wmax = wave_reduce_u32(mine, OpMaxU32());
     const unsigned mypri = pri_base + ((unsigned)(bestj / I) << PRI_SHIFT) + qstep * (unsigned)(bestj % I);
-    const unsigned cand = (mine == wmax && mine != 0u) ? mypri : 0xFFFFFFFFu;
+    const bool holds = mine == wmax && mine != 0u;
+    const unsigned cand = holds ? mypri : 0xFFFFFFFFu;
     const unsigned wpri = wave_reduce_u32(cand, OpMinU32());
-    unsigned long long key =
+    const unsigned long long wkey =
         wmax == 0u ? 0ull : (((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wpri));
+    unsigned long long key = wkey;
+    bool tie = false;
+    if (TRACK) {     // more than one lane at the wave's maximum, or the holder has it twice
+      const unsigned long long hm = __ballot(holds);
+      tie = (hm & (hm - 1ull)) != 0ull || __ballot(holds && lane_tie) != 0ull;
+    }
     if (NW > 1) {
       unsigned long long *slot = slots + (it % 3);
       if (lane == 0) atomicMax(slot, key);
       __syncthreads();
       key = *slot;
       if (tid == 0) slots[(it + 2) % 3] = 0ull;
+      // another wave reached the same maximal distance with a different point
+      if (TRACK) tie = tie || (wmax != 0u && wmax == (unsigned)(key >> 32) && wkey != key);
     }
+    if (TRACK && lane == 0 && (tie || key == 0ull)) *tieflag = 1;
     if (key == 0ull) {
       old = 0;
     } else {
@@ -142,12 +183,25 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
       old = (int)fps_bitrev(p >> PRI_SHIFT, log2bs) + bs * (int)(p & ((1u << PRI_SHIFT) - 1u));
     }
     if (tid == 0) out[it] = old;
-  }
+  };
+  int it = 1;
+  const int tracked_end = tie_out != nullptr ? (tie_iters < m ? tie_iters : m) : 1;
+  for (; it < tracked_end; ++it) iteration(std::true_type{}, it);
+  for (; it < m; ++it) iteration(std::false_type{}, it);
   if (oxyz && tid == 0) {
     oxyz[(m - 1) * 3 + 0] = pts[old * 3 + 0];
     oxyz[(m - 1) * 3 + 1] = pts[old * 3 + 1];
     oxyz[(m - 1) * 3 + 2] = pts[old * 3 + 2];
   }
+  if (tie_out != nullptr) {
+    __syncthreads();                                  // the last tracked iteration's flag store
+    if (tid == 0) tie_out[blockIdx.x] = (m <= tie_iters) ? 1 : *tieflag;   // fewer decisions than asked for
+  }
+}
+
+__global__ void fps_fill_flag_kernel(int *flag, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = v;
 }
 
 // Fallback for clouds too large for the register file: same selection rule, running distances in
@@ -344,7 +398,7 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
 
 template <int T, int E, int I>
 static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float *dataset, int *idxs,
-                           float *new_xyz) {
+                           float *new_xyz, int *tie_out, int tie_iters, const int *prefix_in) {
   const size_t table_bytes = FPS_SLOT_BYTES + (size_t)n * sizeof(float4);
   hipStream_t st = current_stream();
   static int use_table = -1;
@@ -357,10 +411,11 @@ static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float 
                                 160 * 1024);
       big_lds_enabled = true;
     }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(T), table_bytes, st, n, m, bs, log2bs, dataset, idxs, new_xyz);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(T), table_bytes, st, n, m, bs, log2bs, dataset, idxs, new_xyz, tie_out,
+                       tie_iters, prefix_in);
   } else {
     hipLaunchKernelGGL((fps_reg_kernel<T, E, I, false>), dim3(b), dim3(T), FPS_SLOT_BYTES, st, n, m,
-                       bs, log2bs, dataset, idxs, new_xyz);
+                       bs, log2bs, dataset, idxs, new_xyz, tie_out, tie_iters, prefix_in);
   }
 }
 
@@ -410,7 +465,8 @@ __global__ __launch_bounds__(256) void gather_points_grad_kernel(int c, int n, i
 using namespace pwclo;
 
 static void fps_dispatch(int b, int n, int m, const float *dataset, float *temp, int *idxs,
-                         float *new_xyz) {
+                         float *new_xyz, int *tie_out = nullptr, int tie_iters = 0,
+                         const int *prefix_in = nullptr) {
   if (b <= 0 || m <= 0) return;
   PWCLO_REQUIRE(n >= 1, "furthest_point_sampling: n=%d must be >= 1", n);
   PWCLO_REQUIRE((long long)n < (1ll << PRI_SHIFT) * 1ll, "furthest_point_sampling: n=%d too large", n);
@@ -424,7 +480,7 @@ static void fps_dispatch(int b, int n, int m, const float *dataset, float *temp,
   if (T == 1024 && I > 16) { T = 512; E = 0; I = ceil_div(n, 512); }   // VGPR budget at 16 waves
 #define FPS_CASE(TT, EE, II)                                               \
   if (T == TT && E == EE && I <= II) {                                     \
-    launch_fps_reg<TT, EE, II>(b, n, m, bs, log2bs, dataset, idxs, new_xyz);       \
+    launch_fps_reg<TT, EE, II>(b, n, m, bs, log2bs, dataset, idxs, new_xyz, tie_out, tie_iters, prefix_in); \
     check_launch("furthest_point_sampling");                              \
     return;                                                                \
   }
@@ -444,12 +500,14 @@ static void fps_dispatch(int b, int n, int m, const float *dataset, float *temp,
                  FPS_CASE(64, 3, 1) FPS_CASE(64, 3, 2) FPS_CASE(64, 3, 4) FPS_CASE(64, 3, 8) }
 #undef FPS_CASE
   if (n <= 24576) {  // register-resident fallback (large clouds, or a forced T without a case)
-    launch_fps_reg<512, 0, 48>(b, n, m, bs, log2bs, dataset, idxs, new_xyz);
+    launch_fps_reg<512, 0, 48>(b, n, m, bs, log2bs, dataset, idxs, new_xyz, tie_out, tie_iters, prefix_in);
     check_launch("furthest_point_sampling");
     return;
   }
   PWCLO_REQUIRE(temp != nullptr,
                 "furthest_point_sampling: n=%d needs the (b,n) temp buffer pre-filled with 1e10", n);
+  if (tie_out != nullptr)   // the large-cloud samplers keep no tie record: later levels run in full
+    hipLaunchKernelGGL(fps_fill_flag_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, current_stream(), tie_out, b, 1);
   static int coop = -1;
   if (coop < 0) { const char *e = getenv("PWCLO_FPS_COOP"); coop = e ? atoi(e) : 1; }
   const int G = ceil_div(n, COOP_T * 16);                // workgroups per cloud, <= 16 points per thread
@@ -482,6 +540,12 @@ extern "C" void furthest_point_sampling_kernel_wrapper(int b, int n, int m, cons
 extern "C" void furthest_point_sampling_xyz_kernel_wrapper(int b, int n, int m, const float *dataset,
                                                            float *temp, int *idxs, float *new_xyz) {
   fps_dispatch(b, n, m, dataset, temp, idxs, new_xyz);
+}
+
+extern "C" void furthest_point_sampling_chain_kernel_wrapper(int b, int n, int m, const float *dataset,
+                                                             float *temp, int *idxs, float *new_xyz,
+                                                             int *tie_out, int tie_iters, const int *prefix_in) {
+  fps_dispatch(b, n, m, dataset, temp, idxs, new_xyz, tie_out, tie_iters, prefix_in);
 }
 
 extern "C" void gather_points_kernel_wrapper(int b, int c, int n, int npoints, const float *points,

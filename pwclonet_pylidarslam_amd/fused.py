@@ -121,17 +121,18 @@ class FusedSA:
 
 # ---- FPS + sampled coordinates, point-major warp -------------------------------------------------------
 
-def fps_with_xyz(xyz, npoint):
+def fps_with_xyz(xyz, npoint, tie_out=None, tie_iters=0, prefix_in=None):
     """xyz (B,N,3) -> (idx (B,npoint) int32, new_xyz (B,npoint,3)): FPS with the following
-    gather_operation folded into the sampler."""
+    gather_operation folded into the sampler.  ``tie_out`` / ``prefix_in`` (B,) int32: the sampling-chain
+    certificate of include/pwclo_ops.h (furthest_point_sampling_chain_kernel_wrapper)."""
     B, N, _ = xyz.shape
     idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
     tmp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device) if N > 24576 else None
     _lib.annotate(family="fps", units=float(B) * (npoint - 1) * N, iters=npoint - 1,
                   bytes=4.0 * B * (3 * N + 4 * npoint))
-    _lib.call("furthest_point_sampling_xyz_kernel_wrapper", xyz.device, B, N, npoint, _p(xyz), _p(tmp),
-              _p(idx), _p(new_xyz))
+    _lib.call("furthest_point_sampling_chain_kernel_wrapper", xyz.device, B, N, npoint, _p(xyz), _p(tmp),
+              _p(idx), _p(new_xyz), _p(tie_out), int(tie_iters), _p(prefix_in))
     return idx, new_xyz
 
 
@@ -578,6 +579,12 @@ class FusedPWCLONet:
         self.branch = os.environ.get("PWCLO_BRANCH", "1") != "0"   # fork/join streams under graph capture
         # hoisted first layers (per-point partial products, csrc/fused_hoisted.hip); 0 = section-3 kernels
         self.hoist = os.environ.get("PWCLO_HOIST", "1") != "0"
+        # Prefix shortcut of the sampling chain (csrc/sampling.hip "Sampling chains").  Exact and tested, but
+        # OFF by default: ~5 % of 8192-point clouds contain one exact fp32 distance tie among their first
+        # 1023 arg-max decisions, so a 64-cloud launch almost always has a cloud that must run in full --
+        # the later levels' latency stays, and level 1 pays +16 % for the tie bookkeeping (measured:
+        # 13.04k vs 13.03k pairs/s).  Useful for single clouds / small batches.
+        self.fps_chain = os.environ.get("PWCLO_FPS_CHAIN", "0") != "0"
         SA, UP, CV = ((FusedSAHoisted, FusedUpconvHoisted, FusedCostVolumeHoisted) if self.hoist else
                       (FusedSA, FusedUpconv, FusedCostVolume))
         self.pw = pw
@@ -645,13 +652,26 @@ class FusedPWCLONet:
             br = _Branches(x.device, False)
         # The sampling chain of all four levels depends only on the input cloud: it runs ahead on its
         # own branch while the main branch does neighbour search + MLP level by level.
+        # Levels 2..4 sample the previous level's samples: level 1 records whether any of its first
+        # decisions was an exact tie; where none was, the later levels are prefixes (fast path in the
+        # sampler, identical output -- csrc/sampling.hip "Sampling chains").
         samples, ready = [], []
+        npoints = [n for n, _ in self.sa_cfg]
+        chain = self.fps_chain and all(a >= b_ for a, b_ in zip(npoints, npoints[1:])) and len(npoints) > 1
+        flag = torch.empty((x.shape[0],), dtype=torch.int32, device=x.device) if chain else None
         with br.fork(0):
             src = x
-            for npoint, _ in self.sa_cfg:
-                _, src = br.hold(*fps_with_xyz(src, npoint))
+            for lvl, npoint in enumerate(npoints):
+                if chain and lvl == 0:
+                    _, src = br.hold(*fps_with_xyz(src, npoint, tie_out=flag, tie_iters=npoints[1]))
+                elif chain:
+                    _, src = br.hold(*fps_with_xyz(src, npoint, prefix_in=flag))
+                else:
+                    _, src = br.hold(*fps_with_xyz(src, npoint))
                 samples.append(src)
                 ready.append(br.mark(0))
+            if flag is not None:
+                br.hold(flag)
         return dict(B=B, x=x, samples=samples, ready=ready, br=br)
 
     @torch.no_grad()

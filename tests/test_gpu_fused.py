@@ -277,3 +277,32 @@ def test_prediction_module_adapter_matches_forward(cuda):
     assert torch.equal(got_fused, ref_fused)
     assert torch.equal(log["point_cloud"], ref_log["point_cloud"])
     torch.testing.assert_close(got_fused, ref_module, rtol=0, atol=5e-5)
+
+
+def test_fps_chain_prefix_certificate(cuda):
+    """Sampling chains (csrc/sampling.hip): level l+1 samples level l's samples.  Where level l saw no exact
+    tie the later level is a prefix and the sampler returns it directly; where it did (lattice cloud),
+    the flag is raised and the full algorithm runs.  Either way the outputs equal the oracle's FPS of the
+    previous level's samples."""
+    gen = torch.Generator().manual_seed(77)
+    pc1, _, _, _ = synthetic.kitti_like_pair(9, 4096, 2)
+    clouds = [torch.from_numpy(np.ascontiguousarray(pc1[0, :, :3])),                  # lidar-shaped: tie-free
+              torch.randint(-6, 7, (4096, 3), generator=gen).float(),                  # lattice: ties everywhere
+              (torch.rand(4096, 3, generator=gen) * 2 - 1) * 20]                       # uniform: tie-free
+    x = torch.stack(clouds).contiguous()
+    flag = torch.full((3,), -1, dtype=torch.int32, device=cuda)
+    idx0, s0 = fused.fps_with_xyz(x.to(cuda), 1024, tie_out=flag, tie_iters=512)
+    assert torch.equal(idx0.cpu(), O.furthest_point_sampling(x, 1024))
+    assert flag.cpu().tolist() == [0, 1, 0]
+    idx1, s1 = fused.fps_with_xyz(s0, 512, prefix_in=flag)
+    ref1 = O.furthest_point_sampling(s0.cpu().contiguous(), 512)
+    assert torch.equal(idx1.cpu(), ref1)
+    assert torch.equal(idx1[0].cpu(), torch.arange(512, dtype=torch.int32))            # the prefix itself
+    assert not torch.equal(idx1[1].cpu(), torch.arange(512, dtype=torch.int32))        # ties: a different order
+    assert torch.equal(s1.cpu(), torch.stack([s0[b].cpu()[ref1[b].long()] for b in range(3)]))
+    idx2, s2 = fused.fps_with_xyz(s1, 128, prefix_in=flag)                             # third level, same flags
+    assert torch.equal(idx2.cpu(), O.furthest_point_sampling(s1.cpu().contiguous(), 128))
+    # asking for as many decisions as the producer made is refused conservatively (flag raised)
+    flag2 = torch.zeros((3,), dtype=torch.int32, device=cuda)
+    fused.fps_with_xyz(x.to(cuda), 256, tie_out=flag2, tie_iters=256)
+    assert flag2.cpu().tolist() == [1, 1, 1]
