@@ -153,14 +153,15 @@ void furthest_point_sampling_xyz_kernel_wrapper(int b, int n, int m, const float
                                                 float *temp, int *idxs, float *new_xyz);
 
 /* The same for a CHAIN of samplers (the pyramid: each level samples the previous level's samples).
- * Sampling a cloud that is itself an FPS sample list, in sampling order, returns its prefix
- * 0..m-1 whenever every arg-max of the producing call was unique; only exact distance ties, which
- * the two calls break by different index priorities, can change the sequence (csrc/sampling.hip).
- *   tie_out  (b) i32 or NULL: set to 1 for clouds in which one of the first tie_iters arg-max
- *            decisions of THIS call was not unique (or had no candidate), else 0;
- *   prefix_in (b) i32 or NULL: flags written by the call that produced `dataset`; clouds whose flag
- *            is 0 get idx = 0..m-1 and their first m rows directly (m must be <= the tie_iters that call
- *            was given), all others run the full algorithm.  Outputs are identical either way. */
+ * Sampling a cloud that is itself an FPS sample list, in sampling order, returns its prefix 0..m-1
+ * whenever every arg-max of the producing call was unique; an exact two-point distance tie that the
+ * producer resolved over two consecutive iterations shows up as an adjacent pair in an order decided by
+ * the child's position priorities (csrc/sampling.hip, "Sampling chains").
+ *   tie_out  (b, 12) i32 or NULL: per cloud [fallback flag, number of tie events, 8 event iterations, -, -]
+ *            for the first tie_iters - 1 decisions of THIS call (needs m >= tie_iters + 2, else flag = 1);
+ *   prefix_in (b, 12) i32 or NULL: records written by the call that produced `dataset`; clouds whose
+ *            flag is 0 get their result written directly (m must be <= that call's tie_iters), all
+ *            others run the full algorithm.  Outputs are identical either way. */
 void furthest_point_sampling_chain_kernel_wrapper(int b, int n, int m, const float *dataset, float *temp,
                                                   int *idxs, float *new_xyz, int *tie_out, int tie_iters,
                                                   const int *prefix_in);

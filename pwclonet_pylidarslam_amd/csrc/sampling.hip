@@ -55,11 +55,22 @@ __device__ __forceinline__ unsigned fps_bitrev(unsigned v, int bits) {
 // every arg-max of the previous call was unique: sample i+1 maximised the distance to samples 0..i
 // over the whole parent cloud, so it also maximises it over the subset, and the distances are the
 // same fp32 expressions on the same coordinates.  Only a tie -- two points at exactly the same
-// maximal distance, which the two calls would break by different index-based priorities -- can make
-// the sequences differ.  `tie_out`/`tie_iters`: this call records per cloud whether any of its first
-// tie_iters arg-max decisions was not unique (or had no candidate).  `prefix_in`: a later call on this
-// call's samples returns idx = 0..m-1 and the first m rows directly when the flag is clear, and runs
-// the full algorithm otherwise.  Results are identical to always running the full algorithm.
+// maximal distance V, which the two calls break by different index-based priorities -- can make the
+// sequences differ, and the common tie is simple: points a, b tie at iteration i, a is taken, b keeps
+// its distance V (it is far from a) and is taken, alone at V, at iteration i+1.  The child call then
+// sees the same two points tie at list positions i and i+1, takes the one whose POSITION has the
+// better priority, then the other: the prefix with an adjacent pair possibly swapped (and the state
+// after both picks is the same again).  ~5 % of 8192-point lidar clouds have one such tie in their
+// first 1023 decisions (exact fp32 equality among the top candidates).
+//   `tie_out` (FPS_CHAIN_INTS ints per cloud) / `tie_iters`: this call records, for its decisions
+//   1..tie_iters-1, the iterations at which a simple tie happened, or raises the fallback flag for
+//   anything else (tie not resolved alone at V on the next iteration, two ties in a row, no candidate,
+//   more than 8 events).  `prefix_in`: a later call on this call's samples (m <= tie_iters) writes the
+//   prefix with those swaps directly when the flag is clear and runs the full algorithm otherwise.
+// Results are identical to always running the full algorithm (tests/test_gpu_fused.py).
+constexpr int FPS_CHAIN_INTS = 12;    // [0] fallback flag, [1] number of events, [2..9] event iterations
+constexpr int FPS_CHAIN_MAXEV = 8;
+
 template <int T, int E, int I, bool LDS_TABLE>
 __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int log2bs,
                                                     const float *__restrict__ dataset,
@@ -68,11 +79,28 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
                                                     int *__restrict__ tie_out, int tie_iters,
                                                     const int *__restrict__ prefix_in) {
   constexpr int PPT = I << E;
-  if (prefix_in != nullptr && prefix_in[blockIdx.x] == 0) {       // workgroup-uniform
+  if (prefix_in != nullptr && prefix_in[blockIdx.x * FPS_CHAIN_INTS] == 0) {       // workgroup-uniform
+    const int *rec = prefix_in + blockIdx.x * FPS_CHAIN_INTS;
+    const int nev = rec[1];
     const float *src = dataset + (size_t)blockIdx.x * n * 3;
-    for (int i = threadIdx.x; i < m; i += T) idxs[(size_t)blockIdx.x * m + i] = i;
-    if (new_xyz)
-      for (int i = threadIdx.x; i < 3 * m; i += T) new_xyz[(size_t)blockIdx.x * m * 3 + i] = src[i];
+    for (int t = threadIdx.x; t < m; t += T) {
+      int pick = t;
+      for (int e = 0; e < nev; ++e) {
+        const int it = rec[2 + e];                 // tie between list positions it and it+1
+        if ((t == it || t == it + 1) && it + 1 < n) {
+          const unsigned p0 = (fps_bitrev((unsigned)(it & (bs - 1)), log2bs) << PRI_SHIFT) | (unsigned)(it >> log2bs);
+          const unsigned p1 = (fps_bitrev((unsigned)((it + 1) & (bs - 1)), log2bs) << PRI_SHIFT) |
+                              (unsigned)((it + 1) >> log2bs);
+          const int first = p0 < p1 ? it : it + 1;
+          pick = t == it ? first : (first == it ? it + 1 : it);
+        }
+      }
+      idxs[(size_t)blockIdx.x * m + t] = pick;
+      if (new_xyz) {
+        float *d = new_xyz + ((size_t)blockIdx.x * m + t) * 3;
+        d[0] = src[pick * 3 + 0]; d[1] = src[pick * 3 + 1]; d[2] = src[pick * 3 + 2];
+      }
+    }
     return;
   }
   // a sampler wave is one link of a long dependent chain: whenever it can issue, it should, ahead of
@@ -80,8 +108,12 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [3] rotating
-  int *tieflag = reinterpret_cast<int *>(smem + 32);                         // inside the slot header
   float4 *table = reinterpret_cast<float4 *>(smem + FPS_SLOT_BYTES);         // [n] when LDS_TABLE
+  // chain log (only when tie_out): winning value and tie status of iterations 0..tie_iters+1, judged
+  // once after the loop instead of inside it
+  unsigned *cvals = reinterpret_cast<unsigned *>(smem + FPS_SLOT_BYTES + (LDS_TABLE ? (size_t)n * 16 : 0));
+  int *cstat = reinterpret_cast<int *>(cvals + (tie_iters + 2));
+  int *cmeta = reinterpret_cast<int *>(smem + 32);                           // [0] events, [1] fallback (slot header)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -116,8 +148,10 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
   if (tid == 0) {
     out[0] = 0;
     slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull;
-    *tieflag = 0;
+    cmeta[0] = 0; cmeta[1] = 0;
   }
+  if (tie_out != nullptr)
+    for (int i = tid; i < tie_iters + 2; i += T) { cstat[i] = 0; cvals[i] = 0u; }
   __syncthreads();
 
   int old = 0;
@@ -137,7 +171,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
       oxyz[(it - 1) * 3 + 0] = x1; oxyz[(it - 1) * 3 + 1] = y1; oxyz[(it - 1) * 3 + 2] = z1;
     }
     int best = __float_as_int(-1.0f);
-    int best2 = __float_as_int(-1.0f);   // TRACK: the lane's second-largest value (2 more integer ops per point)
+    int best2 = __float_as_int(-1.0f);   // TRACK: the lane's second-largest value (1 more integer op per point)
     int bestj = 0;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -145,7 +179,8 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
       const float d = dx * dx + dy * dy + dz * dz;  // -ffp-contract=off: (a+b)+c, no FMA
       const int d2 = min(__float_as_int(d), td[j]); // == fminf for d >= +0, td >= +0 or td == -1.0f
       td[j] = d2;
-      if (TRACK) best2 = max(best2, min(d2, best));
+      if (TRACK)   // best >= best2 always, so the new runner-up is the median of (best, best2, d2): one instruction
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(best2) : "v"(best), "v"(best2), "v"(d2));
       const bool better = d2 > best;
       bestj = better ? j : bestj;
       best = better ? d2 : best;
@@ -175,7 +210,10 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
       // another wave reached the same maximal distance with a different point
       if (TRACK) tie = tie || (wmax != 0u && wmax == (unsigned)(key >> 32) && wkey != key);
     }
-    if (TRACK && lane == 0 && (tie || key == 0ull)) *tieflag = 1;
+    if (TRACK) {   // log only; judged after the loop
+      if (lane == 0 && (tie || key == 0ull)) cstat[it] = key == 0ull ? 2 : 1;
+      if (tid == 0) cvals[it] = (unsigned)(key >> 32);
+    }
     if (key == 0ull) {
       old = 0;
     } else {
@@ -185,7 +223,8 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
     if (tid == 0) out[it] = old;
   };
   int it = 1;
-  const int tracked_end = tie_out != nullptr ? (tie_iters < m ? tie_iters : m) : 1;
+  // decisions 1..tie_iters-1 matter; the one at tie_iters-1 is only judged two iterations later
+  const int tracked_end = tie_out != nullptr ? (tie_iters + 2 < m ? tie_iters + 2 : m) : 1;
   for (; it < tracked_end; ++it) iteration(std::true_type{}, it);
   for (; it < m; ++it) iteration(std::false_type{}, it);
   if (oxyz && tid == 0) {
@@ -194,14 +233,34 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
     oxyz[(m - 1) * 3 + 2] = pts[old * 3 + 2];
   }
   if (tie_out != nullptr) {
-    __syncthreads();                                  // the last tracked iteration's flag store
-    if (tid == 0) tie_out[blockIdx.x] = (m <= tie_iters) ? 1 : *tieflag;   // fewer decisions than asked for
+    // Judge the log: a tie at iteration i < tie_iters is a simple event iff iteration i+1 had no tie
+    // and won with the same value (the other tied point, alone at V); anything else -> fallback.
+    int *rec = tie_out + blockIdx.x * FPS_CHAIN_INTS;
+    const bool enough = m >= tie_iters + 2;                 // decisions tie_iters-1 and tie_iters both made
+    __syncthreads();
+    if (enough) {
+      for (int i = 1 + tid; i < tie_iters; i += T) {
+        const int st = cstat[i];
+        if (st == 0) continue;
+        if (st == 2 || cstat[i + 1] != 0 || cvals[i + 1] != cvals[i] || (i > 1 && cstat[i - 1] != 0)) {
+          cmeta[1] = 1;
+        } else {
+          const int e = atomicAdd(&cmeta[0], 1);
+          if (e < FPS_CHAIN_MAXEV) rec[2 + e] = i; else cmeta[1] = 1;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      rec[0] = (!enough || cmeta[1] != 0) ? 1 : 0;
+      rec[1] = cmeta[0] < FPS_CHAIN_MAXEV ? cmeta[0] : FPS_CHAIN_MAXEV;
+    }
   }
 }
 
-__global__ void fps_fill_flag_kernel(int *flag, int n, int v) {
+__global__ void fps_fill_flag_kernel(int *rec, int n, int v) {   // fallback flag of n chain records
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = v;
+  if (i < n) { rec[i * FPS_CHAIN_INTS] = v; rec[i * FPS_CHAIN_INTS + 1] = 0; }
 }
 
 // Fallback for clouds too large for the register file: same selection rule, running distances in
@@ -399,7 +458,8 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
 template <int T, int E, int I>
 static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float *dataset, int *idxs,
                            float *new_xyz, int *tie_out, int tie_iters, const int *prefix_in) {
-  const size_t table_bytes = FPS_SLOT_BYTES + (size_t)n * sizeof(float4);
+  const size_t chain_bytes = tie_out ? (size_t)(tie_iters + 2) * 8 : 0;
+  const size_t table_bytes = FPS_SLOT_BYTES + (size_t)n * sizeof(float4) + chain_bytes;
   hipStream_t st = current_stream();
   static int use_table = -1;
   if (use_table < 0) { const char *e = getenv("PWCLO_FPS_TABLE"); use_table = e ? atoi(e) : 1; }
@@ -414,7 +474,7 @@ static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float 
     hipLaunchKernelGGL(kern, dim3(b), dim3(T), table_bytes, st, n, m, bs, log2bs, dataset, idxs, new_xyz, tie_out,
                        tie_iters, prefix_in);
   } else {
-    hipLaunchKernelGGL((fps_reg_kernel<T, E, I, false>), dim3(b), dim3(T), FPS_SLOT_BYTES, st, n, m,
+    hipLaunchKernelGGL((fps_reg_kernel<T, E, I, false>), dim3(b), dim3(T), FPS_SLOT_BYTES + chain_bytes, st, n, m,
                        bs, log2bs, dataset, idxs, new_xyz, tie_out, tie_iters, prefix_in);
   }
 }

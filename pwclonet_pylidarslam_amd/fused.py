@@ -121,10 +121,13 @@ class FusedSA:
 
 # ---- FPS + sampled coordinates, point-major warp -------------------------------------------------------
 
+FPS_CHAIN_INTS = 12      # ints per cloud of a sampling-chain record (csrc/sampling.hip)
+
+
 def fps_with_xyz(xyz, npoint, tie_out=None, tie_iters=0, prefix_in=None):
     """xyz (B,N,3) -> (idx (B,npoint) int32, new_xyz (B,npoint,3)): FPS with the following
-    gather_operation folded into the sampler.  ``tie_out`` / ``prefix_in`` (B,) int32: the sampling-chain
-    certificate of include/pwclo_ops.h (furthest_point_sampling_chain_kernel_wrapper)."""
+    gather_operation folded into the sampler.  ``tie_out`` / ``prefix_in`` (B, FPS_CHAIN_INTS) int32: the
+    sampling-chain record of include/pwclo_ops.h (furthest_point_sampling_chain_kernel_wrapper)."""
     B, N, _ = xyz.shape
     idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
@@ -579,12 +582,9 @@ class FusedPWCLONet:
         self.branch = os.environ.get("PWCLO_BRANCH", "1") != "0"   # fork/join streams under graph capture
         # hoisted first layers (per-point partial products, csrc/fused_hoisted.hip); 0 = section-3 kernels
         self.hoist = os.environ.get("PWCLO_HOIST", "1") != "0"
-        # Prefix shortcut of the sampling chain (csrc/sampling.hip "Sampling chains").  Exact and tested, but
-        # OFF by default: ~5 % of 8192-point clouds contain one exact fp32 distance tie among their first
-        # 1023 arg-max decisions, so a 64-cloud launch almost always has a cloud that must run in full --
-        # the later levels' latency stays, and level 1 pays +16 % for the tie bookkeeping (measured:
-        # 13.04k vs 13.03k pairs/s).  Useful for single clouds / small batches.
-        self.fps_chain = os.environ.get("PWCLO_FPS_CHAIN", "0") != "0"
+        # Prefix shortcut of the sampling chain (csrc/sampling.hip "Sampling chains"): levels 2..4 are
+        # written directly from level 1's tie record (0 = always run the full sampler at every level).
+        self.fps_chain = os.environ.get("PWCLO_FPS_CHAIN", "1") != "0"
         SA, UP, CV = ((FusedSAHoisted, FusedUpconvHoisted, FusedCostVolumeHoisted) if self.hoist else
                       (FusedSA, FusedUpconv, FusedCostVolume))
         self.pw = pw
@@ -658,7 +658,7 @@ class FusedPWCLONet:
         samples, ready = [], []
         npoints = [n for n, _ in self.sa_cfg]
         chain = self.fps_chain and all(a >= b_ for a, b_ in zip(npoints, npoints[1:])) and len(npoints) > 1
-        flag = torch.empty((x.shape[0],), dtype=torch.int32, device=x.device) if chain else None
+        flag = torch.empty((x.shape[0], FPS_CHAIN_INTS), dtype=torch.int32, device=x.device) if chain else None
         with br.fork(0):
             src = x
             for lvl, npoint in enumerate(npoints):

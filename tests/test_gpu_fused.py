@@ -281,28 +281,53 @@ def test_prediction_module_adapter_matches_forward(cuda):
 
 def test_fps_chain_prefix_certificate(cuda):
     """Sampling chains (csrc/sampling.hip): level l+1 samples level l's samples.  Where level l saw no exact
-    tie the later level is a prefix and the sampler returns it directly; where it did (lattice cloud),
-    the flag is raised and the full algorithm runs.  Either way the outputs equal the oracle's FPS of the
-    previous level's samples."""
+    tie the later level is the prefix; a simple two-point tie becomes an adjacent pair ordered by the child's
+    position priorities; anything else (lattice cloud) raises the fallback flag and the full algorithm runs.
+    Either way the outputs equal the oracle's FPS of the previous level's samples."""
     gen = torch.Generator().manual_seed(77)
     pc1, _, _, _ = synthetic.kitti_like_pair(9, 4096, 2)
-    clouds = [torch.from_numpy(np.ascontiguousarray(pc1[0, :, :3])),                  # lidar-shaped: tie-free
+    crafted = (torch.rand(4096, 3, generator=gen) * 2 - 1) * 20        # two mirror pairs tie at decisions 1 and 3
+    crafted[0] = torch.tensor([0.0, 1.0, 0.0])
+    crafted[100], crafted[2077] = torch.tensor([100.0, 1.0, 0.0]), torch.tensor([-100.0, 1.0, 0.0])
+    crafted[333], crafted[3000] = torch.tensor([60.0, 1.0, 70.0]), torch.tensor([-60.0, 1.0, 70.0])
+    clouds = [torch.from_numpy(np.ascontiguousarray(pc1[0, :, :3])),                  # lidar-shaped
               torch.randint(-6, 7, (4096, 3), generator=gen).float(),                  # lattice: ties everywhere
-              (torch.rand(4096, 3, generator=gen) * 2 - 1) * 20]                       # uniform: tie-free
+              (torch.rand(4096, 3, generator=gen) * 2 - 1) * 20,                       # uniform: tie-free
+              crafted]
     x = torch.stack(clouds).contiguous()
-    flag = torch.full((3,), -1, dtype=torch.int32, device=cuda)
-    idx0, s0 = fused.fps_with_xyz(x.to(cuda), 1024, tie_out=flag, tie_iters=512)
+    rec = torch.full((4, fused.FPS_CHAIN_INTS), -1, dtype=torch.int32, device=cuda)
+    idx0, s0 = fused.fps_with_xyz(x.to(cuda), 1024, tie_out=rec, tie_iters=512)
     assert torch.equal(idx0.cpu(), O.furthest_point_sampling(x, 1024))
-    assert flag.cpu().tolist() == [0, 1, 0]
-    idx1, s1 = fused.fps_with_xyz(s0, 512, prefix_in=flag)
+    r = rec.cpu()
+    assert r[:, 0].tolist()[1:] == [1, 0, 0] and r[2, 1].item() == 0
+    assert r[3, 1].item() == 2 and r[3, 2:4].tolist() == [1, 3]                        # the two crafted ties
+    idx1, s1 = fused.fps_with_xyz(s0, 512, prefix_in=rec)
     ref1 = O.furthest_point_sampling(s0.cpu().contiguous(), 512)
     assert torch.equal(idx1.cpu(), ref1)
-    assert torch.equal(idx1[0].cpu(), torch.arange(512, dtype=torch.int32))            # the prefix itself
+    assert torch.equal(idx1[2].cpu(), torch.arange(512, dtype=torch.int32))            # the prefix itself
     assert not torch.equal(idx1[1].cpu(), torch.arange(512, dtype=torch.int32))        # ties: a different order
-    assert torch.equal(s1.cpu(), torch.stack([s0[b].cpu()[ref1[b].long()] for b in range(3)]))
-    idx2, s2 = fused.fps_with_xyz(s1, 128, prefix_in=flag)                             # third level, same flags
+    assert idx1[3, :6].cpu().tolist() != list(range(6))                                # swapped pair(s)
+    assert torch.equal(s1.cpu(), torch.stack([s0[b].cpu()[ref1[b].long()] for b in range(4)]))
+    idx2, s2 = fused.fps_with_xyz(s1, 128, prefix_in=rec)                              # third level, same record
     assert torch.equal(idx2.cpu(), O.furthest_point_sampling(s1.cpu().contiguous(), 128))
-    # asking for as many decisions as the producer made is refused conservatively (flag raised)
-    flag2 = torch.zeros((3,), dtype=torch.int32, device=cuda)
-    fused.fps_with_xyz(x.to(cuda), 256, tie_out=flag2, tie_iters=256)
-    assert flag2.cpu().tolist() == [1, 1, 1]
+    # too few decisions made to certify the ones asked for: flag raised
+    rec2 = torch.zeros((4, fused.FPS_CHAIN_INTS), dtype=torch.int32, device=cuda)
+    fused.fps_with_xyz(x.to(cuda), 256, tie_out=rec2, tie_iters=255)
+    assert rec2[:, 0].cpu().tolist() == [1, 1, 1, 1]
+
+
+def test_fps_chain_matches_full_samplers_on_many_clouds(cuda):
+    """64 lidar-shaped clouds (the benchmark's generator: a few of them contain an exact fp32 tie): three
+    chained levels through the records == three full FPS calls (oracle), bit for bit."""
+    import bench
+    x1, x2 = bench.make_batch(16, 8192, 1000, torch.device("cpu"))
+    x = torch.cat((x1, x2)).permute(0, 2, 1).contiguous()
+    rec = torch.empty((32, fused.FPS_CHAIN_INTS), dtype=torch.int32, device=cuda)
+    _, s0 = fused.fps_with_xyz(x.to(cuda), 2048, tie_out=rec, tie_iters=1024)
+    i1, s1 = fused.fps_with_xyz(s0, 1024, prefix_in=rec)
+    i2, s2 = fused.fps_with_xyz(s1, 256, prefix_in=rec)
+    i3, s3 = fused.fps_with_xyz(s2, 64, prefix_in=rec)
+    assert torch.equal(i1.cpu(), O.furthest_point_sampling(s0.cpu().contiguous(), 1024))
+    assert torch.equal(i2.cpu(), O.furthest_point_sampling(s1.cpu().contiguous(), 256))
+    assert torch.equal(i3.cpu(), O.furthest_point_sampling(s2.cpu().contiguous(), 64))
+    print("chain records: fallback", int(rec[:, 0].sum()), "events", int(rec[:, 1].sum()))
