@@ -14,8 +14,10 @@ from pwclonet_pylidarslam_amd.graphed import PipelinedForward, GraphedForward
 dev = torch.device("cuda:0")
 orig = dict(fps=fused.fps_with_xyz, knn=fused.knn)
 
-def fake_fps(xyz, npoint):
+def fake_fps(xyz, npoint, tie_out=None, tie_iters=0, prefix_in=None):
     idx = torch.arange(npoint, device=xyz.device, dtype=torch.int32).unsqueeze(0).expand(xyz.shape[0], -1).contiguous()
+    if tie_out is not None:
+        tie_out.zero_()
     return idx, xyz[:, :npoint].contiguous()
 
 def fake_knn(k, xyz, new_xyz):
