@@ -7,6 +7,9 @@
 // the block's channel slice), gathers from the channel row (C*N*4 bytes per cloud: L2 resident)
 // and stores 16 bytes, so every wave-store is one contiguous 1 KiB line run.
 // Algorithmic bytes per call: 4*(S*K + C*N + C*S*K).
+#include <stdint.h>
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace pwclo {
@@ -65,6 +68,52 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, 
   }
 }
 
+// LDS-staged variant for n <= GP_LDS_MAXN: the 4-byte gathers of the direct kernel are served by the
+// vector L1 at roughly one 64-byte line per clock and lane group -- ~40 clocks per wave-gather when 64
+// lanes hit a 4 KiB row at random -- which caps it near 3.7-3.9 TB/s of output.  Here a workgroup first
+// copies its channel slice's rows (8 x n floats, coalesced 16-byte loads, L2-resident source) into
+// LDS and gathers from there (a random 64-lane ds_read_b32 costs a few clocks of bank conflicts), then
+// streams GP_CHUNK outputs per channel with non-temporal 16-byte stores: the store stream becomes
+// the only HBM-rate traffic.
+constexpr int GP_LDS_MAXN = 4096;     // 8 channels x 4096 floats = 128 KiB of LDS
+constexpr int GP_CHUNK = 4096;        // outputs per channel and workgroup (16 per thread)
+
+__global__ __launch_bounds__(GP_THREADS) void group_points_lds_kernel(int c, int n, int P,
+                                                                      const float *__restrict__ points,
+                                                                      const int *__restrict__ idx,
+                                                                      float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];   // [GP_CH_PER_BLOCK][n]
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * GP_CH_PER_BLOCK;
+  const int nch = min(GP_CH_PER_BLOCK, c - c0);
+  const float *src = points + ((size_t)b * c + c0) * n;
+  const int total = nch * n;
+  if ((n & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < total; i += GP_THREADS * 4)
+      *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
+  } else {
+    for (int i = threadIdx.x; i < total; i += GP_THREADS) rows[i] = src[i];
+  }
+  __syncthreads();
+  const int *ib = idx + (size_t)b * P;
+  float *ob = out + ((size_t)b * c + c0) * P;
+  const int p_end = min(P, (int)(blockIdx.x + 1) * GP_CHUNK);
+  for (int p = blockIdx.x * GP_CHUNK + threadIdx.x * 4; p < p_end; p += GP_THREADS * 4) {
+    const int4 ii = *reinterpret_cast<const int4 *>(ib + p);
+#pragma unroll
+    for (int l = 0; l < GP_CH_PER_BLOCK; ++l) {
+      if (l < nch) {
+        const float *row = rows + l * n;
+        float *o = ob + (size_t)l * P + p;
+        __builtin_nontemporal_store(row[ii.x], o + 0);
+        __builtin_nontemporal_store(row[ii.y], o + 1);
+        __builtin_nontemporal_store(row[ii.z], o + 2);
+        __builtin_nontemporal_store(row[ii.w], o + 3);
+      }
+    }
+  }
+}
+
 // grad_points[b,c,idx[b,p]] += grad_out[b,c,p]  (fp32 atomics into a zero-filled buffer).
 __global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(
     int c, int n, int P, const float *__restrict__ grad_out, const int *__restrict__ idx,
@@ -93,6 +142,21 @@ extern "C" void group_points_kernel_wrapper(int b, int c, int n, int npoints, in
   const int gy = ceil_div(c, GP_CH_PER_BLOCK);
   const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(idx) & 15) == 0);
+  static int use_lds = -1;
+  if (use_lds < 0) { const char *e = getenv("PWCLO_GROUP_LDS"); use_lds = e ? atoi(e) : 1; }
+  if (vec && use_lds && n <= GP_LDS_MAXN && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
+    const int lds_bytes = GP_CH_PER_BLOCK * n * 4;
+    static bool attr_set = false;
+    if (lds_bytes > 64 * 1024 && !attr_set) {
+      (void)hipFuncSetAttribute((const void *)group_points_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GP_CH_PER_BLOCK * GP_LDS_MAXN * 4);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(group_points_lds_kernel, dim3(ceil_div(P, GP_CHUNK), gy, b), dim3(GP_THREADS), lds_bytes,
+                       current_stream(), c, n, P, points, idx, out);
+    check_launch("group_points");
+    return;
+  }
   if (vec)
     hipLaunchKernelGGL(group_points_kernel<true>, dim3(ceil_div(P / 4, GP_THREADS), gy, b),
                        dim3(GP_THREADS), 0, current_stream(), c, n, P, points, idx, out);
