@@ -226,6 +226,12 @@ void pose_head_fused_kernel_wrapper(int b, int n, const float *emb, const float 
                                     const float *q_prev, const float *t_prev, float *q_out,
                                     float *t_out, float *pose_row, int row_stride);
 
+/* On-device front end of the dataset (slam/dataset/kitti_odometry_dataset.py:375-397, filter_pcd
+ * :149-160): points (n,4) f32 raw velodyne rows (x,y,z,intensity), tr (12) f64 DEVICE array = rows of the
+ * 3x4 calibration matrix Tr; xyz (n,3) f32 = Tr . (x,y,z,1) evaluated in fp64, keep (n) i32 = 1 where the
+ * transformed point is not ground (y <= 1.1) and within |x| < 30, |z| < 30. */
+void kitti_transform_filter_kernel_wrapper(int n, const double *tr, const float *points, float *xyz, int *keep);
+
 /* ---- 4. hoisted variants of section 3 ----------------------------------------------------------
  * The first layer of every grouped MLP is linear in [geometry | feat_centre[s] | feat_nbr[n]]; the
  * feature parts depend on one point only, so W_feat . feat[point] (+ bias) is computed once per

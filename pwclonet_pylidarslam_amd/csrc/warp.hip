@@ -4,6 +4,8 @@
 // reference's term order (PWCLO_utils.py:83-95,117-129) without contraction so the warped
 // coordinates -- which feed the neighbour searches of the refinement levels -- agree with the
 // reference to the last bit wherever torch's own evaluation order is defined.
+#include <stdint.h>
+
 #include "common.hpp"
 
 namespace pwclo {
@@ -76,9 +78,43 @@ __global__ __launch_bounds__(256) void ingest_frames_kernel(int bsz, int n, int 
   dst[2] = src[2];
 }
 
+// Raw KITTI velodyne frame -> camera-frame cloud + keep mask (kitti_odometry_dataset.py:375-397 and
+// filter_pcd :149-160): p' = Tr[:3,:4] . (x, y, z, 1) in fp64 like the reference's numpy matmul on the
+// float64-promoted points, keep = not ground (y' <= 1.1) and |x'| < 30 and |z'| < 30 (strict, as
+// the reference's `<` / `>`), coordinates stored as fp32.  One thread per point; HBM-trivial
+// (16 bytes in, 16 bytes out per point).
+__global__ __launch_bounds__(256) void kitti_transform_filter_kernel(int n, const double *__restrict__ tr,
+                                                                     const float *__restrict__ points,
+                                                                     float *__restrict__ xyz,
+                                                                     int *__restrict__ keep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = *reinterpret_cast<const float4 *>(points + (size_t)i * 4);   // (x, y, z, intensity)
+  const double x = p.x, y = p.y, z = p.z;
+  double o[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    o[r] = ((tr[r * 4 + 0] * x + tr[r * 4 + 1] * y) + tr[r * 4 + 2] * z) + tr[r * 4 + 3];
+  const bool ground = o[1] > 1.1;
+  const bool near = (o[0] < 30.0 && o[0] > -30.0) && (o[2] < 30.0 && o[2] > -30.0);
+  xyz[(size_t)i * 3 + 0] = (float)o[0];
+  xyz[(size_t)i * 3 + 1] = (float)o[1];
+  xyz[(size_t)i * 3 + 2] = (float)o[2];
+  keep[i] = (!ground && near) ? 1 : 0;
+}
+
 }  // namespace pwclo
 
 using namespace pwclo;
+
+extern "C" void kitti_transform_filter_kernel_wrapper(int n, const double *tr, const float *points, float *xyz,
+                                                      int *keep) {
+  if (n <= 0) return;
+  PWCLO_REQUIRE((reinterpret_cast<uintptr_t>(points) & 15) == 0, "kitti_transform_filter: points must be 16-byte aligned%s", "");
+  hipLaunchKernelGGL(kitti_transform_filter_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, current_stream(), n, tr,
+                     points, xyz, keep);
+  check_launch("kitti_transform_filter");
+}
 
 extern "C" void ingest_frames_kernel_wrapper(int b, int n, int n_total, int c, const float *frame1,
                                              const float *frame2, float *out) {

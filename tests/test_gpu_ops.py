@@ -293,3 +293,36 @@ def test_knn_pruned_equals_exhaustive(cuda, k, n, s):
     d0, i0 = E.knn_point(k, x, q, return_dist=True, exhaustive=True)
     assert torch.equal(i1, i0)
     assert torch.equal(d1, d0)
+
+
+def test_kitti_transform_filter_and_sampling(cuda):
+    """the on-device transform + filter equals the NumPy restatement of the dataset code
+    (fp64 arithmetic, coordinates rounded to fp32: identical up to one fp32 ulp of BLAS-vs-fma ordering;
+    same mask), and both sampling modes return npoints survivors."""
+    from oracle.preprocess import transform_filter as ref_tf
+    from pwclonet_pylidarslam_amd import preprocess
+    rng = np.random.default_rng(12)
+    n = 123457
+    pts = np.concatenate([rng.uniform(-70, 70, (n, 2)), rng.uniform(-3, 2, (n, 1)), rng.uniform(0, 1, (n, 1))],
+                         axis=1).astype(np.float32)
+    tr = np.array([[4.3e-4, -0.99997, -8.0e-3, -1.2e-2], [-7.2e-3, 8.1e-3, -0.99994, -5.4e-2],
+                   [0.99997, 4.9e-4, -7.2e-3, -0.292]])                       # KITTI-like calibration
+    q, keep = ref_tf(pts, tr)
+    xyz, k = preprocess.transform_filter(torch.from_numpy(pts).to(cuda), tr)
+    got = xyz.cpu().numpy()
+    ref32 = q.astype(np.float32)
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - ref32.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp > 0).mean() < 1e-3
+    mism = np.nonzero(k.cpu().numpy().astype(bool) != keep)[0]
+    assert len(mism) == 0 or all(np.min(np.abs(np.abs(q[i, [0, 2]]) - 30)) < 1e-9 or abs(q[i, 1] - 1.1) < 1e-9
+                                 for i in mism)
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    cloud = preprocess.kitti_frame_to_cloud(torch.from_numpy(pts).to(cuda), tr, 8192, generator=gen)
+    assert cloud.shape == (8192, 3)
+    kept = q[keep].astype(np.float32)
+    assert set(map(tuple, cloud.cpu().numpy().round(4))) <= set(map(tuple, np.concatenate((kept, got[k.cpu().numpy() > 0])).round(4)))
+    assert len(np.unique(cloud.cpu().numpy(), axis=0)) == 8192          # drawn without replacement
+    fps_cloud = preprocess.kitti_frame_to_cloud(torch.from_numpy(pts).to(cuda), tr, 2048, sample="fps")
+    assert fps_cloud.shape == (2048, 3) and len(np.unique(fps_cloud.cpu().numpy(), axis=0)) == 2048
+    cand = torch.from_numpy(got[k.cpu().numpy() > 0]).unsqueeze(0).contiguous()
+    assert torch.equal(fps_cloud.cpu(), cand[0][O.furthest_point_sampling(cand, 2048)[0].long()])

@@ -217,3 +217,18 @@ def test_loss_module_matches_reference_golden():
         if case["with_exp_weights"]:
             np.testing.assert_allclose(mod.exp_weighting.s_param.grad.numpy(), z[tag + ".grad_s"], rtol=1e-6, atol=0)
             assert list(mod.state_dict().keys()) == ["exp_weighting.s_param"]
+
+
+def test_preprocess_oracle_known_values():
+    """oracle.preprocess.transform_filter against hand-computed values."""
+    from oracle.preprocess import transform_filter
+    tr = [[0, -1, 0, 0.5], [0, 0, -1, -0.25], [1, 0, 0, 2.0]]              # velodyne (x fwd, y left, z up) -> camera
+    pts = np.array([[10, 2, 1, 0.3],        # -> (-1.5, -1.25, 12): kept
+                    [40, 0, 0, 0.1],        # -> z = 42: too far
+                    [5, -31, 0, 0.2],       # -> x = 31.5: too far
+                    [5, 0, -2, 0.9],        # -> y = 1.75 > 1.1: ground
+                    [28, 29.5, -1.35, 0.0]], dtype=np.float32)  # -> (-29, ~1.1, 30): z == 30 is not < 30
+    q, keep = transform_filter(pts, tr)
+    np.testing.assert_allclose(q[0], [-1.5, -1.25, 12.0])
+    assert keep.tolist() == [True, False, False, False, False]
+    assert q.dtype == np.float64
