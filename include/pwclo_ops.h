@@ -226,6 +226,14 @@ void pose_head_fused_kernel_wrapper(int b, int n, const float *emb, const float 
                                     const float *q_prev, const float *t_prev, float *q_out,
                                     float *t_out, float *pose_row, int row_stride);
 
+/* Deterministic (atomics-free) form of group_points_grad / gather_points_grad (nsample = 1): the caller
+ * supplies the inverse of idx per cloud -- perm (b, npoints*nsample) i32 = positions p sorted by idx[b,p]
+ * (stable: ascending p inside a source point), seg (b, n+1) i32 = segment starts -- and every
+ * grad_points[b,c,i] is the sum of grad_out[b,c,perm[seg[i]..seg[i+1])] in that order.  No zero fill. */
+void group_points_grad_sorted_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                             const float *grad_out, const int *perm, const int *seg,
+                                             float *grad_points);
+
 /* On-device front end of the dataset (slam/dataset/kitti_odometry_dataset.py:375-397, filter_pcd
  * :149-160): points (n,4) f32 raw velodyne rows (x,y,z,intensity), tr (12) f64 DEVICE array = rows of the
  * 3x4 calibration matrix Tr; xyz (n,3) f32 = Tr . (x,y,z,1) evaluated in fp64, keep (n) i32 = 1 where the

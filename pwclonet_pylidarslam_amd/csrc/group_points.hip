@@ -128,9 +128,52 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(
     atomicAdd(grad_points + ((size_t)b * c + l) * n + ii, grad_out[((size_t)b * c + l) * P + p]);
 }
 
+// Atomics-free, run-to-run deterministic scatter-add: the (b, p) -> n map is
+// inverted on the host side of the C ABI (a stable sort of idx per cloud: `perm` lists the p of every
+// source point n contiguously and in ascending p, `seg` holds the n+1 segment boundaries); one thread
+// per (cloud, source point) then adds its segment in that fixed order for the block's channel slice.
+// grad_points needs no zero fill (every element is written).  Same values as the atomic kernel up to
+// fp32 summation order.
+__global__ __launch_bounds__(GP_THREADS) void group_points_grad_sorted_kernel(
+    int c, int n, int P, const float *__restrict__ grad_out, const int *__restrict__ perm,
+    const int *__restrict__ seg, float *__restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * GP_CH_PER_BLOCK;
+  const int nch = min(GP_CH_PER_BLOCK, c - c0);
+  const int i = blockIdx.x * GP_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const int *pb = perm + (size_t)b * P;
+  const int s0 = seg[(size_t)b * (n + 1) + i], s1 = seg[(size_t)b * (n + 1) + i + 1];
+  float acc[GP_CH_PER_BLOCK];
+#pragma unroll
+  for (int l = 0; l < GP_CH_PER_BLOCK; ++l) acc[l] = 0.f;
+  const float *g = grad_out + ((size_t)b * c + c0) * P;
+  for (int j = s0; j < s1; ++j) {
+    const int p = pb[j];
+#pragma unroll
+    for (int l = 0; l < GP_CH_PER_BLOCK; ++l)
+      if (l < nch) acc[l] += g[(size_t)l * P + p];
+  }
+#pragma unroll
+  for (int l = 0; l < GP_CH_PER_BLOCK; ++l)
+    if (l < nch) grad_points[((size_t)b * c + c0 + l) * n + i] = acc[l];
+}
+
 }  // namespace pwclo
 
 using namespace pwclo;
+
+extern "C" void group_points_grad_sorted_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                                        const float *grad_out, const int *perm, const int *seg,
+                                                        float *grad_points) {
+  if (b <= 0 || c <= 0 || n <= 0) return;
+  const long long P64 = (long long)npoints * nsample;
+  PWCLO_REQUIRE(P64 < (1ll << 31) && b <= 65535, "group_points_grad_sorted: npoints*nsample=%lld or b=%d too large",
+                P64, b);
+  hipLaunchKernelGGL(group_points_grad_sorted_kernel, dim3(ceil_div(n, GP_THREADS), ceil_div(c, GP_CH_PER_BLOCK), b),
+                     dim3(GP_THREADS), 0, current_stream(), c, n, (int)P64, grad_out, perm, seg, grad_points);
+  check_launch("group_points_grad_sorted");
+}
 
 extern "C" void group_points_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
                                             const float *points, const int *idx, float *out) {

@@ -140,6 +140,24 @@ def group_points_grad(grad_out, idx, n):
     return out
 
 
+def scatter_grad_deterministic(grad_out, idx, n):
+    """Atomics-free ``group_points_grad`` (idx (B,S,K), grad_out (B,C,S,K)) / ``gather_points_grad`` (idx
+    (B,M), grad_out (B,C,M)) -> (B,C,n): same sums in a fixed order (ascending output position per
+    source point), bit-identical from run to run.  The inverse index is a stable torch sort."""
+    _float(grad_out, "grad_out"); _int(idx, "idx"); _gpu(grad_out, idx)
+    B, C = grad_out.shape[0], grad_out.shape[1]
+    flat = idx.reshape(B, -1)
+    P = flat.shape[1]
+    order = torch.sort(flat, dim=1, stable=True)
+    perm = order.indices.to(torch.int32).contiguous()
+    bounds = torch.arange(n + 1, device=idx.device, dtype=flat.dtype).unsqueeze(0).expand(B, -1).contiguous()
+    seg = torch.searchsorted(order.values.contiguous(), bounds).to(torch.int32).contiguous()
+    out = torch.empty((B, C, n), dtype=torch.float32, device=grad_out.device)
+    _lib.call("group_points_grad_sorted_kernel_wrapper", grad_out.device, B, C, n, P, 1, _p(grad_out), _p(perm),
+              _p(seg), _p(out))
+    return out
+
+
 # ---- native replacements of pure-PyTorch ops (include/pwclo_ops.h section 2) ---------------------
 
 def knn_point(nsample, xyz, new_xyz, return_dist=False, exhaustive=None):

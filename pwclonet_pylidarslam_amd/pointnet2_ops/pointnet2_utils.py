@@ -28,6 +28,22 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
+_DETERMINISTIC = None
+
+
+def deterministic_grads(enable=None):
+    """Backward of gather / grouping through the atomics-free sorted scatter (``_ext.scatter_grad_
+    deterministic``) instead of the reference's fp32 atomics.  Default: env PWCLO_DETERMINISTIC_GRADS
+    (0), or whatever ``torch.are_deterministic_algorithms_enabled()`` says."""
+    global _DETERMINISTIC
+    if enable is not None:
+        _DETERMINISTIC = bool(enable)
+    if _DETERMINISTIC is not None:
+        return _DETERMINISTIC
+    import os
+    return os.environ.get("PWCLO_DETERMINISTIC_GRADS", "0") != "0" or torch.are_deterministic_algorithms_enabled()
+
+
 class GatherOperation(Function):
     @staticmethod
     def forward(ctx, features, idx):
@@ -39,6 +55,8 @@ class GatherOperation(Function):
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
+        if deterministic_grads():
+            return _ext.scatter_grad_deterministic(grad_out.contiguous(), idx, ctx.n), None
         return _ext.gather_points_grad(grad_out.contiguous(), idx, ctx.n), None
 
 
@@ -92,6 +110,8 @@ class GroupingOperation(Function):
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
+        if deterministic_grads():
+            return _ext.scatter_grad_deterministic(grad_out.contiguous(), idx, ctx.n), torch.zeros_like(idx)
         return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n), torch.zeros_like(idx)
 
 

@@ -326,3 +326,29 @@ def test_kitti_transform_filter_and_sampling(cuda):
     assert fps_cloud.shape == (2048, 3) and len(np.unique(fps_cloud.cpu().numpy(), axis=0)) == 2048
     cand = torch.from_numpy(got[k.cpu().numpy() > 0]).unsqueeze(0).contiguous()
     assert torch.equal(fps_cloud.cpu(), cand[0][O.furthest_point_sampling(cand, 2048)[0].long()])
+
+
+@pytest.mark.parametrize("b,c,n,s,k", [(2, 16, 500, 300, 8), (3, 67, 1024, 2048, 4), (1, 3, 64, 256, 32)])
+def test_deterministic_scatter_grad(cuda, b, c, n, s, k):
+    """Atomics-free backward of grouping / gather: same sums as the oracle within fp32
+    summation order, bit-identical across runs, and reachable through the autograd Functions."""
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pointnet2_utils as PU
+    gen = torch.Generator().manual_seed(b * 1000 + n)
+    idx = torch.randint(0, n, (b, s, k), generator=gen, dtype=torch.int32)
+    go = torch.randn(b, c, s, k, generator=gen)
+    ref = O.group_points_grad(go, idx, n)
+    out1 = E.scatter_grad_deterministic(g(go, cuda), g(idx, cuda), n)
+    out2 = E.scatter_grad_deterministic(g(go, cuda), g(idx, cuda), n)
+    assert torch.equal(out1, out2)
+    torch.testing.assert_close(out1.cpu(), ref, rtol=1e-5, atol=1e-5)
+    idx1 = idx[:, :, 0].contiguous()                                   # gather form (B,M)
+    go1 = go[:, :, :, 0].contiguous()
+    torch.testing.assert_close(E.scatter_grad_deterministic(g(go1, cuda), g(idx1, cuda), n).cpu(),
+                               O.gather_points_grad(go1, idx1, n), rtol=1e-5, atol=1e-5)
+    PU.deterministic_grads(True)
+    try:
+        feat = torch.randn(b, c, n, generator=gen).to(cuda).requires_grad_(True)
+        PU.grouping_operation(feat, g(idx, cuda)).mul(g(go, cuda)).sum().backward()
+        assert torch.equal(feat.grad, out1)
+    finally:
+        PU.deterministic_grads(False)
