@@ -416,6 +416,7 @@ extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, in
   SAH_CASE(16, 16, 32, 32, false, 2, 8)     // psa_2
   SAH_CASE(32, 32, 64, 16, false, 1, 16)    // psa_3
   SAH_CASE(64, 64, 128, 16, false, 1, 16)   // psa_4
+  if (tiles_h(b, s, 16, 1) <= 2048) { SAH_CASE(128, 64, 64, 16, false, 1, 4) }   // flow_feature_encoding, coarse
   SAH_CASE(128, 64, 64, 16, false, 1, 16)   // flow_feature_encoding
 #undef SAH_CASE
   set_error(PWCLO_EINVAL, "sa_fused_h: no kernel for mlp=(%d,%d,%d) nsample=%d level0=%d", c1, c2, c3, k, (int)lvl0);
@@ -457,6 +458,8 @@ extern "C" void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xy
   CVHArgs a{xyz1, u2, xyz1, v2, first, idx, packed_w, out, b, s, s, k};
   static bool attr = false;
   constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(4, 8) + layer_floats(8, 4));
-  launch_h<16>(cv_b_h_kernel<4, 1, 16>, attr, lds, tiles_h(b, s, 4, 1), a);
+  static bool attr_s = false;
+  if (tiles_h(b, s, 4, 1) <= 2048) launch_h<4>(cv_b_h_kernel<4, 1, 4>, attr_s, lds, tiles_h(b, s, 4, 1), a);
+  else launch_h<16>(cv_b_h_kernel<4, 1, 16>, attr, lds, tiles_h(b, s, 4, 1), a);
   check_launch("cv_fused_b_h");
 }

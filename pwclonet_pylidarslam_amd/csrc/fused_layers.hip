@@ -711,7 +711,11 @@ extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const flo
   constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(8, 8) + layer_floats(8, 4));
   static bool attr32 = false, attr16 = false, attr8 = false, attr16w = false, attr8w = false, attr6 = false;
   static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);
-  if (kp == 6) launch_persistent<8>(cv_a2_dense6_kernel<8>, attr6, lds, (long long)b * ((s + 7) / 8), a);
+  static bool attr6s = false;
+  const long long t6 = (long long)b * ((s + 7) / 8);
+  if (kp == 6 && t6 <= 2048)   // coarse level: 4-wave workgroups reach twice as many CUs
+    launch_persistent<4>(cv_a2_dense6_kernel<4>, attr6s, lds, t6, a);
+  else if (kp == 6) launch_persistent<8>(cv_a2_dense6_kernel<8>, attr6, lds, t6, a);
   else if (kp == 32) launch_persistent<8>(cv_a2_kernel<32, 2, 8>, attr32, lds, tiles_of(b, s, 32, 2), a);
   else if (kp == 16 && wide) launch_persistent<16>(cv_a2_kernel<16, 1, 16>, attr16w, lds, tiles_of(b, s, 16, 1), a);
   else if (kp == 16) launch_persistent<8>(cv_a2_kernel<16, 2, 8>, attr16, lds, tiles_of(b, s, 16, 2), a);
