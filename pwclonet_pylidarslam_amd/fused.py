@@ -262,7 +262,8 @@ class FusedCostVolume:
                   _p(feat2), _p(idx_q), _p(self.w_a1), _p(pix))
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
         _lib.annotate(family="mlp", kernel={32: "cv_a2_kernel<32, 2, 8>", 16: "cv_a2_kernel<16, 1, 16>", 8: "cv_a2_kernel<8, 1, 16>",
-                                            6: "cv_a2_dense6_kernel<8>"}[kp],
+                                            6: "cv_a2_dense6_kernel<8>" if B * ((S + 7) // 8) > 2048
+                                            else "cv_a2_dense6_kernel<4>"}[kp],
                       flops=2.0 * B * S * kq * self.macs_a2,
                       bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
@@ -445,7 +446,7 @@ class FusedUpconvHoisted:
         B, S, _ = xyz2.shape
         N, K = xyz1.shape[1], idx.shape[2]
         pooled = torch.empty((B, S, 64), dtype=torch.float32, device=xyz2.device)
-        _lib.annotate(family="mlp", flops=2.0 * B * S * K * (self.macs - 64 * 128),
+        _lib.annotate(family="mlp", kernel="upconv_h_kernel<8, 1, 16>", flops=2.0 * B * S * K * (self.macs - 64 * 128),
                       bytes=4.0 * B * (S * K * (1 + 3 + 128) + 3 * S + 64 * S))
         _lib.call("upconv_fused_h_kernel_wrapper", xyz2.device, B, N, S, K, _p(xyz2), _p(xyz1), _p(pre),
                   _p(idx), _p(self.packed), _p(pooled))
@@ -499,13 +500,15 @@ class FusedCostVolumeHoisted:
             idx_q = knn(kq, xyz2, xyz1)
         kp = cv_pix_slots(kq)
         pix = torch.empty((B, S * kp, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", flops=2.0 * B * S * kq * (self.macs_a1 - 2 * c * 128),
+        _lib.annotate(family="mlp", kernel="cv_a1_h_kernel<%d, 1, 16>" % kp,
+                      flops=2.0 * B * S * kq * (self.macs_a1 - 2 * c * 128),
                       bytes=4.0 * B * (S * kq * (1 + 3 + 128 + 64) + S * (3 + 128)))
         _lib.call("cv_fused_a1_h_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(u), _p(xyz2), _p(v), _p(idx_q),
                   _p(self.w_a1), _p(pix))
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
         _lib.annotate(family="mlp", kernel={32: "cv_a2_kernel<32, 2, 8>", 16: "cv_a2_kernel<16, 1, 16>", 8: "cv_a2_kernel<8, 1, 16>",
-                                            6: "cv_a2_dense6_kernel<8>"}[kp],
+                                            6: "cv_a2_dense6_kernel<8>" if B * ((S + 7) // 8) > 2048
+                                            else "cv_a2_dense6_kernel<4>"}[kp],
                       flops=2.0 * B * S * kq * self.macs_a2,
                       bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
@@ -514,7 +517,8 @@ class FusedCostVolumeHoisted:
             idx = knn(k, xyz1, xyz1)
         (v2,) = run_linear_jobs([(self.job_v2, first)])
         out = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", flops=2.0 * B * S * k * (self.macs_b - (c + 64) * 128),
+        _lib.annotate(family="mlp", kernel="cv_b_h_kernel<4, 1, %d>" % (4 if B * ((S * 4 + 15) // 16) <= 2048 else 16),
+                      flops=2.0 * B * S * k * (self.macs_b - (c + 64) * 128),
                       bytes=4.0 * B * (S * k * (1 + 3 + 128 + 64) + S * (3 + 128 + 64)))
         _lib.call("cv_fused_b_h_kernel_wrapper", dev, B, S, k, _p(xyz1), _p(u2), _p(v2), _p(first), _p(idx),
                   _p(self.w_b), _p(out))
