@@ -112,9 +112,9 @@ struct SAHArgs {
   int B, N, S, K;
 };
 
-template <int B1, int B2, int B3, int KP, int P, int W, bool XYZ_ONLY>
+template <int B1, int B2, int B3, int KP, int P, int W, bool XYZ_ONLY, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
-  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats(B1, B2), W3 = layer_floats(B2, B3);
+  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<BF3>(B1, B2), W3 = layer_floats_any<BF3>(B2, B3);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2 + W3);
   __syncthreads();
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
         for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
       mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
     }
-    mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
-    mlp_layer<B2, B3, P, false>(h3, h2, lds_w + W1 + W2, lane);   // its ReLU is applied after the pool
+    mlp_layer_any<BF3, B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    mlp_layer_any<BF3, B2, B3, P, false>(h3, h2, lds_w + W1 + W2, lane);   // its ReLU is applied after the pool
     constexpr int GROUP = KP < 16 ? KP : 16;
     constexpr int BPQ = KP > 16 ? KP / 16 : 1;
 #pragma unroll
@@ -184,10 +184,10 @@ struct UpHArgs {
   int B, N, S, K;
 };
 
-template <int KP, int P, int W>
+template <int KP, int P, int W, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
   constexpr int B1 = 8, B2 = 4;
-  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats(B1, B2);
+  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<BF3>(B1, B2);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2);
   __syncthreads();
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
     mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
-    mlp_layer<B1, B2, P, false>(h2, h1, lds_w + W1, lane);        // its ReLU is applied after the pool
+    mlp_layer_any<BF3, B1, B2, P, false>(h2, h1, lds_w + W1, lane);   // its ReLU is applied after the pool
     constexpr int GROUP = KP < 16 ? KP : 16;
 #pragma unroll
     for (int o = 0; o < B2; ++o)
@@ -245,10 +245,10 @@ struct CVHArgs {
   int B, N, S, K;
 };
 
-template <int KP, int P, int W>
+template <int KP, int P, int W, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
   constexpr int B1 = 8, B2 = 4, B3 = 4;
-  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats(B1, B2), W3 = layer_floats(B2, B3);
+  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<BF3>(B1, B2), W3 = layer_floats_any<BF3>(B2, B3);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2 + W3);
   __syncthreads();
@@ -278,8 +278,8 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) h1[o][p] = ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o);
     mlp_layer_init<1, B1, P, true, 3>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // geometry(10)
-    mlp_layer<B1, B2, P, true>(h2, h1, lds_w + W1, lane);
-    mlp_layer<B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
+    mlp_layer_any<BF3, B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    mlp_layer_any<BF3, B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
 #pragma unroll
     for (int o = 0; o < B3; ++o)
 #pragma unroll
@@ -289,9 +289,9 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
   }
 }
 
-template <int KP, int P, int W>
+template <int KP, int P, int W, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
-  constexpr int WX = layer_floats(1, 4), W1 = layer_floats(4, 8), W2 = layer_floats(8, 4);
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<BF3>(4, 8), W2 = layer_floats_any<BF3>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, WX + W1 + W2);
   __syncthreads();
@@ -325,8 +325,11 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) h1[o][p] = ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o);
     mlp_layer<1, 4, P, true, 3>(enc, geo, lds_w, lane);
-    mlp_layer_init<4, 8, P, true>(h1, enc, lds_w + WX, lane, [&](int o, int p) { return h1[o][p]; });
-    mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+    if constexpr (BF3)
+      mlp_layer_bf3_init<4, 8, P, true>(h1, enc, lds_w + WX, lane, [&](int o, int p) { return h1[o][p]; });
+    else
+      mlp_layer_init<4, 8, P, true>(h1, enc, lds_w + WX, lane, [&](int o, int p) { return h1[o][p]; });
+    mlp_layer_any<BF3, 8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
     // softmax over the neighbours, weighted sum of the gathered first-aggregate rows
     constexpr int GROUP = KP < 16 ? KP : 16;
     const float NEG_INF = __int_as_float(0xff800000);
@@ -405,10 +408,16 @@ extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, in
   const bool lvl0 = pre == nullptr;
 #define SAH_CASE(A1, A2, A3, KP, XYZ, PP, WW)                                                         \
   if (c1 == A1 && c2 == A2 && c3 == A3 && kp == KP && lvl0 == XYZ) {                                  \
-    static bool attr = false;                                                                         \
+    static bool attr = false, attr3 = false;                                                          \
     constexpr int lds = 4 * (layer_floats(1, A1 / 16) + layer_floats(A1 / 16, A2 / 16) +               \
                              layer_floats(A2 / 16, A3 / 16));                                          \
-    launch_h<WW>(sa_h_kernel<A1 / 16, A2 / 16, A3 / 16, KP, PP, WW, XYZ>, attr, lds, tiles_h(b, s, KP, PP), a); \
+    constexpr int lds3 = 4 * (layer_floats(1, A1 / 16) + layer_floats_any<true>(A1 / 16, A2 / 16) +    \
+                              layer_floats_any<true>(A2 / 16, A3 / 16));                               \
+    if (bf16x3_enabled())                                                                             \
+      launch_h<WW>(sa_h_kernel<A1 / 16, A2 / 16, A3 / 16, KP, PP, WW, XYZ, true>, attr3, lds3,          \
+                   tiles_h(b, s, KP, PP), a);                                                         \
+    else                                                                                              \
+      launch_h<WW>(sa_h_kernel<A1 / 16, A2 / 16, A3 / 16, KP, PP, WW, XYZ>, attr, lds, tiles_h(b, s, KP, PP), a); \
     check_launch("sa_fused_h");                                                                       \
     return;                                                                                           \
   }
@@ -428,9 +437,11 @@ extern "C" void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const 
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 8, "upconv_fused_h: nsample=%d outside [1,8]", k);
   UpHArgs a{xyz2, xyz1, pre, idx, packed_w, out, b, n, s, k};
-  static bool attr = false;
+  static bool attr = false, attr3 = false;
   constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4));
-  launch_h<16>(upconv_h_kernel<8, 1, 16>, attr, lds, tiles_h(b, s, 8, 1), a);
+  constexpr int lds3 = 4 * (layer_floats(1, 8) + layer_floats_bf3(8, 4));
+  if (bf16x3_enabled()) launch_h<16>(upconv_h_kernel<8, 1, 16, true>, attr3, lds3, tiles_h(b, s, 8, 1), a);
+  else launch_h<16>(upconv_h_kernel<8, 1, 16>, attr, lds, tiles_h(b, s, 8, 1), a);
   check_launch("upconv_fused_h");
 }
 
@@ -442,7 +453,16 @@ extern "C" void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const f
   CVHArgs a{xyz1, u, xyz2, v, nullptr, idx, packed_w, pix, b, n, s, k};
   const int kp = cv_pix_slots(k);
   constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4) + layer_floats(4, 4));
-  static bool a32 = false, a16 = false, a8 = false, a6 = false;
+  constexpr int lds3 = 4 * (layer_floats(1, 8) + layer_floats_bf3(8, 4) + layer_floats_bf3(4, 4));
+  static bool a32 = false, a16 = false, a8 = false, a6 = false, b32 = false, b16 = false, b8 = false, b6 = false;
+  if (bf16x3_enabled()) {
+    if (kp == 6) launch_h<16>(cv_a1_h_kernel<6, 1, 16, true>, b6, lds3, tiles_h(b, s, 6, 1), a);
+    else if (kp == 32) launch_h<16>(cv_a1_h_kernel<32, 1, 16, true>, b32, lds3, tiles_h(b, s, 32, 1), a);
+    else if (kp == 16) launch_h<16>(cv_a1_h_kernel<16, 1, 16, true>, b16, lds3, tiles_h(b, s, 16, 1), a);
+    else launch_h<16>(cv_a1_h_kernel<8, 1, 16, true>, b8, lds3, tiles_h(b, s, 8, 1), a);
+    check_launch("cv_fused_a1_h");
+    return;
+  }
   if (kp == 6) launch_h<16>(cv_a1_h_kernel<6, 1, 16>, a6, lds, tiles_h(b, s, 6, 1), a);
   else if (kp == 32) launch_h<16>(cv_a1_h_kernel<32, 1, 16>, a32, lds, tiles_h(b, s, 32, 1), a);
   else if (kp == 16) launch_h<16>(cv_a1_h_kernel<16, 1, 16>, a16, lds, tiles_h(b, s, 16, 1), a);
@@ -458,8 +478,12 @@ extern "C" void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xy
   CVHArgs a{xyz1, u2, xyz1, v2, first, idx, packed_w, out, b, s, s, k};
   static bool attr = false;
   constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(4, 8) + layer_floats(8, 4));
-  static bool attr_s = false;
-  if (tiles_h(b, s, 4, 1) <= 2048) launch_h<4>(cv_b_h_kernel<4, 1, 4>, attr_s, lds, tiles_h(b, s, 4, 1), a);
+  static bool attr_s = false, attr3 = false, attr3_s = false;
+  constexpr int lds3 = 4 * (layer_floats(1, 4) + layer_floats_bf3(4, 8) + layer_floats_bf3(8, 4));
+  const bool small = tiles_h(b, s, 4, 1) <= 2048;
+  if (bf16x3_enabled() && small) launch_h<4>(cv_b_h_kernel<4, 1, 4, true>, attr3_s, lds3, tiles_h(b, s, 4, 1), a);
+  else if (bf16x3_enabled()) launch_h<16>(cv_b_h_kernel<4, 1, 16, true>, attr3, lds3, tiles_h(b, s, 4, 1), a);
+  else if (small) launch_h<4>(cv_b_h_kernel<4, 1, 4>, attr_s, lds, tiles_h(b, s, 4, 1), a);
   else launch_h<16>(cv_b_h_kernel<4, 1, 16>, attr, lds, tiles_h(b, s, 4, 1), a);
   check_launch("cv_fused_b_h");
 }

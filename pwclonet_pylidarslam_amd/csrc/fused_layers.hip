@@ -261,9 +261,9 @@ __global__ __launch_bounds__(W * 64) void cv_a1_kernel(CVArgs a) {
 }
 
 // a2: enc = mlp_conv_xyz_1(geo); w = softmax_k(mlp2_convs([enc | feat])); out = sum_k w * feat.
-template <int KP, int P, int W>
+template <int KP, int P, int W, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
-  constexpr int WX = layer_floats(1, 4), W1 = layer_floats(8, 8), W2 = layer_floats(8, 4);
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<BF3>(8, 8), W2 = layer_floats_any<BF3>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, WX + W1 + W2);
   __syncthreads();
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) cat[m][p] = enc[m][p];
     f32x4 h1[8][P], h2[4][P];
-    mlp_layer<8, 8, P, true>(h1, cat, lds_w + WX, lane);
-    mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+    mlp_layer_any<BF3, 8, 8, P, true>(h1, cat, lds_w + WX, lane);
+    mlp_layer_any<BF3, 8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
     constexpr int GROUP = KP < 16 ? KP : 16;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
@@ -321,10 +321,10 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
 //   i >= 6: query 6 + h,  neighbour 2p + (i-6) -- "split" segment, lanes 6,7 / 14,15 of the three
 //           blocks: reduced in-lane across the blocks, then across the lane pair (one DPP step).
 // cv_a1 writes the per-pixel features densely as (B, S, 6, 64) for this kernel.
-template <int W>
+template <int W, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
   constexpr int P = 3;
-  constexpr int WX = layer_floats(1, 4), W1 = layer_floats(8, 8), W2 = layer_floats(8, 4);
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<BF3>(8, 8), W2 = layer_floats_any<BF3>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, WX + W1 + W2);
   __syncthreads();
@@ -349,15 +349,31 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
       geo[0][p] = geometry_block(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
       load_row_blocks<4>(&cat[4][p], P, a.pix + (((size_t)b * a.S + s) * 6 + k) * 64, g);
     }
-    f32x4 enc[4][P];
-    mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
+    f32x4 h2[4][P];
+    if constexpr (BF3) {
+      // the split operands of three blocks at once do not fit the register file: one 16-pixel block at a time
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+      for (int p = 0; p < P; ++p) {
+        f32x4 g1[1][1] = {{geo[0][p]}}, enc1[4][1], c1[8][1], h1[8][1], o1[4][1];
+        mlp_layer<1, 4, 1, true>(enc1, g1, lds_w, lane);
 #pragma unroll
-      for (int p = 0; p < P; ++p) cat[m][p] = enc[m][p];
-    f32x4 h1[8][P], h2[4][P];
-    mlp_layer<8, 8, P, true>(h1, cat, lds_w + WX, lane);
-    mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+        for (int m = 0; m < 4; ++m) { c1[m][0] = enc1[m][0]; c1[4 + m][0] = cat[4 + m][p]; }
+        mlp_layer_bf3<8, 8, 1, true>(h1, c1, lds_w + WX, lane);
+        mlp_layer_bf3<8, 4, 1, true>(o1, h1, lds_w + WX + W1, lane);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) h2[o][p] = o1[o][0];
+      }
+    } else {
+      f32x4 enc[4][P];
+      mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int p = 0; p < P; ++p) cat[m][p] = enc[m][p];
+      f32x4 h1[8][P];
+      mlp_layer<8, 8, P, true>(h1, cat, lds_w + WX, lane);
+      mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+    }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       f32x4 res[P];
@@ -713,6 +729,15 @@ extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const flo
   static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);
   static bool attr6s = false;
   const long long t6 = (long long)b * ((s + 7) / 8);
+  if (bf16x3_enabled() && (kp == 6 || kp == 32)) {     // experimental split path (mlp_core.hpp)
+    constexpr int lds3 = 4 * (layer_floats(1, 4) + layer_floats_bf3(8, 8) + layer_floats_bf3(8, 4));
+    static bool b6 = false, b6s = false, b32 = false;
+    if (kp == 6 && t6 <= 2048) launch_persistent<4>(cv_a2_dense6_kernel<4, true>, b6s, lds3, t6, a);
+    else if (kp == 6) launch_persistent<8>(cv_a2_dense6_kernel<8, true>, b6, lds3, t6, a);
+    else launch_persistent<8>(cv_a2_kernel<32, 2, 8, true>, b32, lds3, tiles_of(b, s, 32, 2), a);
+    check_launch("cv_fused_a2");
+    return;
+  }
   if (kp == 6 && t6 <= 2048)   // coarse level: 4-wave workgroups reach twice as many CUs
     launch_persistent<4>(cv_a2_dense6_kernel<4>, attr6s, lds, t6, a);
   else if (kp == 6) launch_persistent<8>(cv_a2_dense6_kernel<8>, attr6, lds, t6, a);

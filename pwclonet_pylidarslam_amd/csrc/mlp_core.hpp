@@ -133,6 +133,115 @@ __device__ __forceinline__ void mlp_layer(f32x4 (&out)[NBO][P], const f32x4 (&in
   });
 }
 
+// ---- opt-in: fp32-accurate layer on the bf16 matrix pipe (PWCLO_BF16X3=1, default off) -------------
+// Every operand is split into three bf16 terms (x = hi + mid + lo, each rounded to nearest) and six of the
+// nine cross products are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (the dropped mid*lo, lo*mid,
+// lo*lo terms are below 2^-24 relative).  A K = 32 instruction consumes TWO 16-channel blocks: lane group g
+// supplies k = 8g..8g+7, taken as its four registers of block 2*mp and its four of block 2*mp+1, so the
+// accumulator-is-the-next-operand property of the fp32 path carries over; the packed weights hold, per
+// (o, mp) tile, [split][lane][8 bf16] in the matching order (fused.py: pack_layer_bf3).  96 matrix cycles
+// per 32 input channels instead of 256, paid for with ~5.5 VALU instructions per split activation.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct Split3 { bf16x8 hi, mid, lo; };
+
+__device__ __forceinline__ Split3 split3(const f32x4 a, const f32x4 b) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  Split3 s;
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const bf16x2 h = {(__bf16)v[i], (__bf16)v[i + 1]};
+    const float r0 = v[i] - (float)h[0], r1 = v[i + 1] - (float)h[1];
+    const bf16x2 m = {(__bf16)r0, (__bf16)r1};
+    const float q0 = r0 - (float)m[0], q1 = r1 - (float)m[1];
+    const bf16x2 l = {(__bf16)q0, (__bf16)q1};
+    s.hi[i] = h[0]; s.hi[i + 1] = h[1];
+    s.mid[i] = m[0]; s.mid[i + 1] = m[1];
+    s.lo[i] = l[0]; s.lo[i + 1] = l[1];
+  }
+  return s;
+}
+
+constexpr int BF3_TILE_FLOATS = 768;   // 3 splits x 64 lanes x 8 bf16 = 3 KiB per (o, mp) tile
+constexpr int layer_floats_bf3(int nbi, int nbo) { return nbo * (nbi / 2) * BF3_TILE_FLOATS + nbo * 16; }
+
+template <int NBI, int NBO, int P, bool RELU, typename Init>
+__device__ __forceinline__ void mlp_layer_bf3_init(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
+                                                   const float *w, int lane, Init init) {
+  static_assert(NBI % 2 == 0, "a K = 32 step consumes two 16-channel blocks");
+  constexpr int NP = NBI / 2;
+  Split3 x[NP][P];
+#pragma unroll
+  for (int mp = 0; mp < NP; ++mp)
+#pragma unroll
+    for (int p = 0; p < P; ++p) x[mp][p] = split3(in[2 * mp][p], in[2 * mp + 1][p]);
+  const float *wl = w + lane * 4;                      // 16 bytes per lane and split
+#pragma unroll
+  for (int o = 0; o < NBO; ++o) {
+    f32x4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = init(o, p);
+#pragma unroll
+    for (int mp = 0; mp < NP; ++mp) {
+      const float *t = wl + (o * NP + mp) * BF3_TILE_FLOATS;
+      const bf16x8 whi = *reinterpret_cast<const bf16x8 *>(t);
+      const bf16x8 wmid = *reinterpret_cast<const bf16x8 *>(t + 256);
+      const bf16x8 wlo = *reinterpret_cast<const bf16x8 *>(t + 512);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        f32x4 c = acc[p];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, x[mp][p].hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, x[mp][p].lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, x[mp][p].mid, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, x[mp][p].hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, x[mp][p].mid, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, x[mp][p].hi, c, 0, 0, 0);
+        acc[p] = c;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (RELU) {
+        f32x4 v = acc[p];
+        v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+        out[o][p] = v;
+      } else {
+        out[o][p] = acc[p];
+      }
+    }
+  }
+}
+
+template <int NBI, int NBO, int P, bool RELU>
+__device__ __forceinline__ void mlp_layer_bf3(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
+                                              const float *w, int lane) {
+  const float *bias = w + NBO * (NBI / 2) * BF3_TILE_FLOATS + 4 * (lane >> 4);
+  mlp_layer_bf3_init<NBI, NBO, P, RELU>(out, in, w, lane, [&](int o, int) {
+    return *reinterpret_cast<const f32x4 *>(bias + 16 * o);
+  });
+}
+
+// Layer dispatch used by the stack kernels: BF3 selects the split path (needs an even NBI).
+template <bool BF3, int NBI, int NBO, int P, bool RELU>
+__device__ __forceinline__ void mlp_layer_any(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
+                                              const float *w, int lane) {
+  if constexpr (BF3 && NBI % 2 == 0) mlp_layer_bf3<NBI, NBO, P, RELU>(out, in, w, lane);
+  else mlp_layer<NBI, NBO, P, RELU>(out, in, w, lane);
+}
+template <bool BF3>
+constexpr int layer_floats_any(int nbi, int nbo) {
+  return (BF3 && nbi % 2 == 0) ? layer_floats_bf3(nbi, nbo) : layer_floats(nbi, nbo);
+}
+
+// Read at every launch (not cached) so that one process can pack and run both formats: the packed
+// weights a wrapper receives must have been produced under the same setting (fused.py reads it too).
+static inline int bf16x3_enabled() {
+  const char *e = getenv("PWCLO_BF16X3");
+  return e ? atoi(e) : 0;
+}
+
 // Hoisting.  The first layer of a grouped MLP is linear in its concatenated input
 // [geometry(q,p) | feat_centre[s] | feat_nbr[n]], and the feature parts depend on ONE point, not on
 // the (query, neighbour) pixel.  W_feat . feat[point] (+ bias) is therefore computed once per

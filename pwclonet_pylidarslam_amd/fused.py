@@ -48,6 +48,36 @@ def pack_layer(w, b, phys_map, nbo=None):
     return torch.cat((wp, bias)).contiguous()
 
 
+def bf16x3_enabled():
+    import os
+    return os.environ.get("PWCLO_BF16X3", "0") != "0"
+
+
+def pack_layer_bf3(w, b, phys_map, nbo=None):
+    """Pack one folded layer for ``mlp_layer_bf3`` (csrc/mlp_core.hpp): per (o, mp) tile [split][lane][8 bf16],
+    lane = 16*g + row, element t of lane group g = physical channel 16*(2*mp + t//4) + 4*g + t%4; the three
+    splits are the round-to-nearest bf16 terms hi, mid, lo of every weight.  Returned as float32 storage."""
+    cout, _ = w.shape
+    nbi = len(phys_map) // 16
+    assert len(phys_map) == 16 * nbi and nbi % 2 == 0
+    nbo = nbo or (cout + 15) // 16
+    pm = torch.as_tensor(phys_map, dtype=torch.long, device=w.device)
+    wphys = torch.zeros((16 * nbo, 16 * nbi), dtype=torch.float32, device=w.device)
+    valid = pm >= 0
+    wphys[:cout, valid] = w[:, pm[valid]]
+    # (o, row, mp, half, g, r) -> (o, mp, g, row, half, r): element t = 4*half + r of lane 16*g + row
+    wt = wphys.view(nbo, 16, nbi // 2, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(nbo, nbi // 2, 64, 8)
+    hi = wt.to(torch.bfloat16)
+    r1 = wt - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    tiles = torch.stack((hi, mid, lo), dim=2).contiguous()            # (o, mp, split, lane, 8)
+    packed = tiles.view(torch.int16).reshape(-1).view(torch.float32)
+    bias = torch.zeros(16 * nbo, dtype=torch.float32, device=w.device)
+    bias[:cout] = b
+    return torch.cat((packed, bias)).contiguous()
+
+
 def chain_map(cout_prev, nb):
     """Physical->original map of a layer fed by the previous layer's (padded) output."""
     return [c if c < cout_prev else -1 for c in range(16 * nb)]
@@ -63,15 +93,16 @@ def stack_macs(shared_mlp):
     return sum(int(l.conv.weight.shape[0]) * int(l.conv.weight.shape[1]) for l in shared_mlp)
 
 
-def pack_stack(shared_mlp, first_map):
+def pack_stack(shared_mlp, first_map, split=False):
     """Pack every layer of a SharedMLP whose first layer reads the physical order `first_map`.
-    Returns (packed float tensor, [padded widths])."""
+    Returns (packed float tensor, [padded widths]).  ``split``: layers with an even number of input
+    blocks use the bf16x3 format when that path is enabled (kernels built on mlp_layer_any)."""
     parts, widths = [], []
     pm = first_map
     for layer in shared_mlp:
         w, b = fold_conv_bn(layer)
         nbo = (w.shape[0] + 15) // 16
-        parts.append(pack_layer(w, b, pm, nbo))
+        parts.append((pack_layer_any if split else pack_layer)(w, b, pm, nbo))
         widths.append(16 * nbo)
         pm = chain_map(w.shape[0], nbo)
     return torch.cat(parts).contiguous(), widths
@@ -233,7 +264,7 @@ class FusedCostVolume:
         self.w_a1, w = pack_stack(module.mlp_convs, geo + [10 + c for c in range(2 * c1)])
         assert w == [128, 64, 64]
         wx1, wd = pack_stack(module.mlp_conv_xyz_1, geo)
-        w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)))     # [enc (64) | feat (64)], :133
+        w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)), split=cv_pix_slots(module.nsample_q) in (6, 32))     # [enc (64) | feat (64)], :133
         assert wd == [64] and wd2 == [128, 64]
         self.w_a2 = torch.cat((wx1, w2)).contiguous()
         wx2, _ = pack_stack(module.mlp_conv_xyz_2, geo)
@@ -365,13 +396,21 @@ def _zeros_like_bias(w):
     return torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
 
 
+def pack_layer_any(w, b, phys_map, nbo=None):
+    """``pack_layer_bf3`` when the bf16x3 path is on and the layer has an even number of 16-channel input
+    blocks (csrc/mlp_core.hpp: mlp_layer_any / layer_floats_any), ``pack_layer`` otherwise."""
+    if bf16x3_enabled() and (len(phys_map) // 16) % 2 == 0:
+        return pack_layer_bf3(w, b, phys_map, nbo)
+    return pack_layer(w, b, phys_map, nbo)
+
+
 def _pack_rest(layers, cout_prev):
     """Pack layers 2.. of a stack fed by a previous layer with `cout_prev` real outputs."""
     parts, widths = [], []
     for layer in layers:
         w, b = fold_conv_bn(layer)
         nbo = (w.shape[0] + 15) // 16
-        parts.append(pack_layer(w, b, chain_map(cout_prev, (cout_prev + 15) // 16), nbo))
+        parts.append(pack_layer_any(w, b, chain_map(cout_prev, (cout_prev + 15) // 16), nbo))
         widths.append(16 * nbo)
         cout_prev = w.shape[0]
     return parts, widths
@@ -471,7 +510,7 @@ class FusedCostVolumeHoisted:
         assert widths == [64, 64]
         self.w_a1 = torch.cat([first] + rest).contiguous()
         wx1, wd = pack_stack(module.mlp_conv_xyz_1, geo)
-        w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)))
+        w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)), split=cv_pix_slots(module.nsample_q) in (6, 32))
         assert wd == [64] and wd2 == [128, 64]
         self.w_a2 = torch.cat((wx1, w2)).contiguous()
         wx2, _ = pack_stack(module.mlp_conv_xyz_2, kstep_major_map(10))
@@ -479,7 +518,7 @@ class FusedCostVolumeHoisted:
         w3, b3 = fold_conv_bn(lb[0])                                   # [enc2 (64) | feat1 (C) | first (64)]
         self.job_u2 = LinearJob(w3[:, 64:64 + c], b3)
         self.job_v2 = LinearJob(w3[:, 64 + c:], _zeros_like_bias(w3))
-        first_b = pack_layer(w3[:, :64], _zeros_like_bias(w3), list(range(64)), 8)
+        first_b = pack_layer_any(w3[:, :64], _zeros_like_bias(w3), list(range(64)), 8)
         rest_b, wdb = _pack_rest(lb[1:], 128)
         assert wdb == [64]
         self.w_b = torch.cat([wx2, first_b] + rest_b).contiguous()

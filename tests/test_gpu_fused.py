@@ -331,3 +331,29 @@ def test_fps_chain_matches_full_samplers_on_many_clouds(cuda):
     assert torch.equal(i2.cpu(), O.furthest_point_sampling(s1.cpu().contiguous(), 256))
     assert torch.equal(i3.cpu(), O.furthest_point_sampling(s2.cpu().contiguous(), 64))
     print("chain records: fallback", int(rec[:, 0].sum()), "events", int(rec[:, 1].sum()))
+
+
+@pytest.mark.parametrize("case", ["n1024_b2", "n8192_b1"])
+def test_bf16x3_split_path_matches_golden(cuda, case, monkeypatch):
+    """PWCLO_BF16X3=1 (opt-in): the stack layers with an even number of input blocks run as three-term bf16
+    splits on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Same bounds as the fp32-MFMA path: pose
+    within 1e-4 of the reference's golden output, level-3 features / cost volume within 2e-5 / 5e-5, and
+    within 2e-6 of the fp32-MFMA path itself."""
+    z = np.load(os.path.join(GOLDEN, "pwclonet_%s.npz" % case))
+    meta = json.loads(str(z["meta"]))
+    if meta["generator"] == "uniform":
+        pc1, pc2 = synthetic.uniform_pair(meta["seed"], meta["npoints"], meta["batch"])
+    else:
+        pc1, pc2, _, _ = synthetic.kitti_like_pair(meta["seed"], meta["npoints"], meta["batch"])
+    x1 = torch.from_numpy(pc1[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    x2 = torch.from_numpy(pc2[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    net = _net(cuda)
+    pose32, inter32 = fused.FusedPWCLONet(net)(x1, x2, return_intermediates=True)
+    monkeypatch.setenv("PWCLO_BF16X3", "1")
+    pose, inter = fused.FusedPWCLONet(net)(x1, x2, return_intermediates=True)     # packs and launches the split format
+    ref = torch.from_numpy(z["pose_params"])
+    assert (pose.cpu() - ref).abs().max().item() < 1e-4
+    close(pm(inter["f13"]), torch.from_numpy(z["f1.psa_3.new_features"]), rel=2e-5)
+    close(pm(inter["flow"]), torch.from_numpy(z["cv3.out"]), rel=5e-5)
+    assert (pose - pose32).abs().max().item() < 2e-6
+    assert not torch.equal(inter["flow"], inter32["flow"])                        # it really is the other arithmetic
