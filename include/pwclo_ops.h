@@ -240,6 +240,17 @@ void group_points_grad_sorted_kernel_wrapper(int b, int c, int n, int npoints, i
  * transformed point is not ground (y <= 1.1) and within |x| < 30, |z| < 30. */
 void kitti_transform_filter_kernel_wrapper(int n, const double *tr, const float *points, float *xyz, int *keep);
 
+/* KITTI-360 variant (slam/dataset/kitti_360_dataset_2.py:113-123; no calibration transform): xyz (n,3) = the
+ * first three columns, keep = not ground (z >= ground_z, the reference's -(1.73 - 0.3)) and |x| < near and
+ * |y| < near, compared in fp32.  n may span several frames laid end to end (b*n rows). */
+void kitti360_filter_kernel_wrapper(int n, float ground_z, float near, const float *points, float *xyz, int *keep);
+
+/* Stable per-frame compaction after either filter: keep, pos (b,n) i32 with pos = inclusive prefix sum of
+ * keep along each frame; kept row i of frame f is copied to out[f, pos-1] (out (b,cap,3) f32, zero-filled by
+ * the caller: zero rows are never selected by furthest_point_sampling), counts (b) i32 = min(kept, cap). */
+void compact_frames_kernel_wrapper(int b, int n, int cap, const int *keep, const int *pos, const float *xyz,
+                                   float *out, int *counts);
+
 /* ---- 4. hoisted variants of section 3 ----------------------------------------------------------
  * The first layer of every grouped MLP is linear in [geometry | feat_centre[s] | feat_nbr[n]]; the
  * feature parts depend on one point only, so W_feat . feat[point] (+ bias) is computed once per

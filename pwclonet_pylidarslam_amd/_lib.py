@@ -43,6 +43,8 @@ SIGNATURES = {
     "ingest_pairs_kernel_wrapper": ([_i, _i, _F, _F, _F], None),
     "ingest_frames_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F], None),
     "kitti_transform_filter_kernel_wrapper": ([_i, _F, _F, _F, _F], None),
+    "kitti360_filter_kernel_wrapper": ([_i, ctypes.c_float, ctypes.c_float, _F, _F, _F], None),
+    "compact_frames_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F, _F], None),
     "group_points_grad_sorted_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, _F, _F, _F], None),
     "upconv_fused_kernel_wrapper": ([_i] * 4 + [_F] * 6, None),
     "pointwise_fused_kernel_wrapper": ([_i] * 7 + [_F] * 5, None),

@@ -103,6 +103,42 @@ __global__ __launch_bounds__(256) void kitti_transform_filter_kernel(int n, cons
   keep[i] = (!ground && near) ? 1 : 0;
 }
 
+// KITTI-360 front end (slam/dataset/kitti_360_dataset_2.py:113-123): raw velodyne rows stay in the sensor
+// frame; keep = not ground (z >= ground_z) and |x| < near and |y| < near, compared in fp32 as NumPy
+// compares a float32 column with a Python scalar.  xyz = the first three columns.
+__global__ __launch_bounds__(256) void kitti360_filter_kernel(int n, float ground_z, float near,
+                                                              const float *__restrict__ points,
+                                                              float *__restrict__ xyz, int *__restrict__ keep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = *reinterpret_cast<const float4 *>(points + (size_t)i * 4);
+  const bool ground = p.z < ground_z;
+  const bool close = (p.x < near && p.x > -near) && (p.y < near && p.y > -near);
+  xyz[(size_t)i * 3 + 0] = p.x;
+  xyz[(size_t)i * 3 + 1] = p.y;
+  xyz[(size_t)i * 3 + 2] = p.z;
+  keep[i] = (!ground && close) ? 1 : 0;
+}
+
+// Stable per-frame compaction of the kept rows: pos = inclusive scan of keep along the frame, row i of
+// frame f goes to out[f, pos-1]; rows >= count stay as the caller zero-filled them (the sampler never
+// selects zero rows).  Rows beyond `cap` are dropped (the caller sizes cap >= max count).
+__global__ __launch_bounds__(256) void compact_frames_kernel(int n, int cap, const int *__restrict__ keep,
+                                                             const int *__restrict__ pos,
+                                                             const float *__restrict__ xyz,
+                                                             float *__restrict__ out, int *__restrict__ counts) {
+  const int f = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t row = (size_t)f * n + i;
+  const int p = pos[row];
+  if (keep[row] != 0 && p <= cap) {
+    float *d = out + ((size_t)f * cap + (p - 1)) * 3;
+    d[0] = xyz[row * 3 + 0]; d[1] = xyz[row * 3 + 1]; d[2] = xyz[row * 3 + 2];
+  }
+  if (i == n - 1) counts[f] = p < cap ? p : cap;
+}
+
 }  // namespace pwclo
 
 using namespace pwclo;
@@ -114,6 +150,24 @@ extern "C" void kitti_transform_filter_kernel_wrapper(int n, const double *tr, c
   hipLaunchKernelGGL(kitti_transform_filter_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, current_stream(), n, tr,
                      points, xyz, keep);
   check_launch("kitti_transform_filter");
+}
+
+extern "C" void kitti360_filter_kernel_wrapper(int n, float ground_z, float near, const float *points, float *xyz,
+                                               int *keep) {
+  if (n <= 0) return;
+  PWCLO_REQUIRE((reinterpret_cast<uintptr_t>(points) & 15) == 0, "kitti360_filter: points must be 16-byte aligned%s", "");
+  hipLaunchKernelGGL(kitti360_filter_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, current_stream(), n, ground_z,
+                     near, points, xyz, keep);
+  check_launch("kitti360_filter");
+}
+
+extern "C" void compact_frames_kernel_wrapper(int b, int n, int cap, const int *keep, const int *pos,
+                                              const float *xyz, float *out, int *counts) {
+  if (b <= 0 || n <= 0) return;
+  PWCLO_REQUIRE(b <= 65535 && cap > 0, "compact_frames: b=%d cap=%d out of range", b, cap);
+  hipLaunchKernelGGL(compact_frames_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, current_stream(), n, cap,
+                     keep, pos, xyz, out, counts);
+  check_launch("compact_frames");
 }
 
 extern "C" void ingest_frames_kernel_wrapper(int b, int n, int n_total, int c, const float *frame1,

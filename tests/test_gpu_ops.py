@@ -328,6 +328,63 @@ def test_kitti_transform_filter_and_sampling(cuda):
     assert torch.equal(fps_cloud.cpu(), cand[0][O.furthest_point_sampling(cand, 2048)[0].long()])
 
 
+def _raw_frames(seed, b, n):
+    rng = np.random.default_rng(seed)
+    return np.concatenate([rng.uniform(-60, 60, (b, n, 2)), rng.uniform(-2.5, 2, (b, n, 1)),
+                           rng.uniform(0, 1, (b, n, 1))], axis=2).astype(np.float32)
+
+
+def test_kitti360_filter_compaction_and_batched_sampling(cuda):
+    """SURVEY section 8 f2, KITTI-360 variant + batching: mask and coordinates bitwise equal to the NumPy
+    restatement of filter_pcd; the per-frame stable compaction equals boolean indexing, zero padded; the
+    batched furthest point sampling of the packed frames equals the oracle's sampler on each frame's survivors
+    (padding changes nothing: zero rows are skipped and bs = 512 for every N >= 512)."""
+    from oracle.preprocess import kitti360_filter as ref_filter
+    from pwclonet_pylidarslam_amd import preprocess
+    b, n, m = 3, 30011, 384
+    pts = _raw_frames(31, b, n)
+    pts[1, :, :2] *= 2.0                                  # fewer survivors in frame 1
+    pts[2, 100:200, :3] = pts[2, 0:100, :3]               # duplicated rows survive in order
+    dev = torch.from_numpy(pts).to(cuda)
+    xyz, keep = preprocess.kitti360_filter(dev, 35.0)
+    refs = [ref_filter(pts[f], 35.0) for f in range(b)]
+    for f in range(b):
+        assert np.array_equal(xyz[f].cpu().numpy().view(np.int32), refs[f][0].view(np.int32))
+        assert np.array_equal(keep[f].cpu().numpy().astype(bool), refs[f][1])
+    packed, counts = preprocess.compact(xyz, keep)
+    assert packed.shape == (b, n, 3)
+    for f in range(b):
+        kept = refs[f][0][refs[f][1]]
+        assert int(counts[f]) == len(kept)
+        assert np.array_equal(packed[f, :len(kept)].cpu().numpy(), kept)
+        assert not packed[f, len(kept):].any()
+    small, c2 = preprocess.compact(xyz, keep, cap=5000)   # survivors beyond cap are dropped, counts clipped
+    assert small.shape == (b, 5000, 3) and c2.tolist() == [min(int(c), 5000) for c in counts]
+    assert torch.equal(small, packed[:, :5000])
+    clouds, counts2 = preprocess.frames_to_clouds(dev, m, dataset="kitti360", near_threshold=35.0)
+    assert torch.equal(counts2, counts) and clouds.shape == (b, m, 3)
+    for f in range(b):
+        kept = torch.from_numpy(np.ascontiguousarray(refs[f][0][refs[f][1]])).unsqueeze(0)
+        ref_idx = O.furthest_point_sampling(kept, m)[0].long()
+        assert torch.equal(clouds[f].cpu(), kept[0][ref_idx])
+    single, _ = preprocess.kitti360_filter(dev[0], 35.0)  # (n,4) form
+    assert torch.equal(single, xyz[0])
+
+
+def test_kitti_batched_frames_to_clouds(cuda):
+    """Batched KITTI-odometry front end (one calibration for the batch) equals the per-frame path."""
+    from pwclonet_pylidarslam_amd import preprocess
+    tr = np.array([[4.3e-4, -0.99997, -8.0e-3, -1.2e-2], [-7.2e-3, 8.1e-3, -0.99994, -5.4e-2],
+                   [0.99997, 4.9e-4, -7.2e-3, -0.292]])
+    pts = _raw_frames(32, 2, 20000)
+    dev = torch.from_numpy(pts).to(cuda)
+    clouds, counts = preprocess.frames_to_clouds(dev, 256, dataset="kitti", tr=tr)
+    for f in range(2):
+        one = preprocess.kitti_frame_to_cloud(dev[f], tr, 256, sample="fps")
+        assert torch.equal(clouds[f], one)
+        assert int(counts[f]) == int(preprocess.transform_filter(dev[f], tr)[1].sum())
+
+
 @pytest.mark.parametrize("b,c,n,s,k", [(2, 16, 500, 300, 8), (3, 67, 1024, 2048, 4), (1, 3, 64, 256, 32)])
 def test_deterministic_scatter_grad(cuda, b, c, n, s, k):
     """Atomics-free backward of grouping / gather: same sums as the oracle within fp32

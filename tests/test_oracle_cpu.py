@@ -232,3 +232,17 @@ def test_preprocess_oracle_known_values():
     np.testing.assert_allclose(q[0], [-1.5, -1.25, 12.0])
     assert keep.tolist() == [True, False, False, False, False]
     assert q.dtype == np.float64
+
+
+def test_preprocess_oracle_kitti360_known_values():
+    """oracle.preprocess.kitti360_filter against hand-computed values (kitti_360_dataset_2.py:113-123)."""
+    from oracle.preprocess import kitti360_filter
+    pts = np.array([[10, 2, 1, 0.3],          # kept
+                    [10, 2, -1.5, 0.3],       # z < -1.43: ground
+                    [10, 2, -1.43, 0.3],      # float32(-1.43) is not < float32(-1.43): kept
+                    [35, 0, 0, 0.1],          # x == near: not < near
+                    [0, -34.9, 0, 0.1],       # kept
+                    [0, -35.1, 0, 0.1]], dtype=np.float32)
+    xyz, keep = kitti360_filter(pts, 35.0)
+    assert keep.tolist() == [True, False, True, False, True, False]
+    assert xyz.dtype == np.float32 and xyz.shape == (6, 3)
