@@ -21,6 +21,8 @@ algorithmic FLOP / measured time against the fp32 MFMA peak, `traffic` from the 
 passes (profiles/pmc_traffic.json), `mlp_family` the same figure over every MFMA-stack launch, and
 `kernels` lists the other families (FPS, knn) with the bound that applies to them.  `cpu_baseline`: the CPU oracle
 (bit-identical to the imported reference) on a few B=1 pairs on this box's host cores.
+`variants` (N=1 only, after everything above): the same step with the opt-in PWCLO_BF16X3=1 stack layers, for
+comparison; it is never the headline `value`.
 """
 import argparse
 import json
@@ -189,6 +191,35 @@ def cpu_baseline(net, npoints, pairs):
                       % (pairs, npoints, torch.get_num_threads(), dt)}
 
 
+def bf16x3_variant(args, dev, x1, x2, pose_ref, streams):
+    """The same step with the opt-in PWCLO_BF16X3=1 stack layers (fp32 operands split into three bf16 terms on
+    the bf16 matrix pipe, fp32 accumulate), measured AFTER the headline region on the same
+    inputs and weights.  Reported beside the headline number, never as it."""
+    from pwclonet_pylidarslam_amd.graphed import PipelinedForward
+    os.environ["PWCLO_BF16X3"] = "1"
+    try:
+        torch.manual_seed(1234)
+        net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(dev), scalar_last=False,
+                            log_mode=args.log_mode)).to(dev).eval()
+        net.prepare_fused()
+        pipe = PipelinedForward(net, depth=args.inflight, streams=streams)
+        pipe.prepare(x1, x2)
+        for _ in range(args.warmup):
+            pipe(x1, x2)
+        dist_util.fence(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pose = pipe(x1, x2)[0]
+        dist_util.fence(dev)
+        dt = time.perf_counter() - t0
+    finally:
+        os.environ["PWCLO_BF16X3"] = "0"
+    return {"value": args.batch * args.steps / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt / args.steps,
+            "max_abs_pose_diff_vs_headline": float((pose - pose_ref).abs().max()),
+            "note": "opt-in PWCLO_BF16X3=1; not the headline path.  The pose difference is dominated by one pair whose "
+                    "level-1 neighbour list differs between the two paths after the warp (DESIGN.md section 2)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +243,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16)
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra (untimed-region) measurement of the opt-in bf16x3 split path")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_util.env_world()
@@ -286,6 +319,9 @@ def main():
             roof, kernels = roofline_objects(instrumented_pass(net, x1, x2))
             out["roofline"] = roof
             out["kernels"] = kernels
+        if not args.no_variants and world == 1 and pipe is not None and not args.unfused \
+                and args.pipeline == "whole" and os.environ.get("PWCLO_BF16X3", "0") == "0":
+            out["variants"] = {"bf16x3": bf16x3_variant(args, dev, x1, x2, pose.clone(), pipe.streams)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(net, args.npoints, args.cpu_pairs)
         print(json.dumps(out), flush=True)

@@ -71,13 +71,16 @@ class PipelinedForward:
     Throughput tool: each call returns the (static) output tensor of the slot it used, valid once
     that slot's stream has been synchronised (``wait(slot)`` / ``wait_all()``)."""
 
-    def __init__(self, net, depth=2):
+    def __init__(self, net, depth=2, streams=None):
         # single-branch graphs: two multi-branch graphs in flight serialise on this runtime
         # (measured: 5.35 ms/step with branches vs 4.0 ms without, 2 in flight)
         import os
         branch = os.environ.get("PWCLO_PIPE_BRANCH", "0") != "0"
         self.slots = [GraphedForward(net, branch=branch) for _ in range(depth)]
-        self.streams = None
+        # `streams`: reuse another pipeline's streams -- the runtime binds every new stream to the next
+        # hardware queue round-robin, so a second set of streams in one process can collide with itself
+        self.streams = list(streams) if streams is not None else None
+        assert self.streams is None or len(self.streams) == depth
         self.events = [None] * depth
         self._next = 0
 
