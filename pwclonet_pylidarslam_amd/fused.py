@@ -53,6 +53,18 @@ def bf16x3_enabled():
     return os.environ.get("PWCLO_BF16X3", "0") != "0"
 
 
+def _kname(name, split_capable=True):
+    """Kernel name as rocprofv3 prints it: the stack kernels carry a trailing `bool BF3` template argument."""
+    return name[:-1] + (", true>" if split_capable and bf16x3_enabled() else ", false>")
+
+
+def _a2_kernel_name(kp, B, S):
+    if kp == 6:
+        return _kname("cv_a2_dense6_kernel<%d>" % (8 if B * ((S + 7) // 8) > 2048 else 4))
+    return _kname({32: "cv_a2_kernel<32, 2, 8>", 16: "cv_a2_kernel<16, 1, 16>", 8: "cv_a2_kernel<8, 1, 16>"}[kp],
+                  split_capable=kp == 32)
+
+
 def pack_layer_bf3(w, b, phys_map, nbo=None):
     """Pack one folded layer for ``mlp_layer_bf3`` (csrc/mlp_core.hpp): per (o, mp) tile [split][lane][8 bf16],
     lane = 16*g + row, element t of lane group g = physical channel 16*(2*mp + t//4) + 4*g + t%4; the three
@@ -292,9 +304,7 @@ class FusedCostVolume:
         _lib.call("cv_fused_a1_kernel_wrapper", dev, B, N, S, kq, self.c, _p(xyz1), _p(feat1), _p(xyz2),
                   _p(feat2), _p(idx_q), _p(self.w_a1), _p(pix))
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel={32: "cv_a2_kernel<32, 2, 8>", 16: "cv_a2_kernel<16, 1, 16>", 8: "cv_a2_kernel<8, 1, 16>",
-                                            6: "cv_a2_dense6_kernel<8>" if B * ((S + 7) // 8) > 2048
-                                            else "cv_a2_dense6_kernel<4>"}[kp],
+        _lib.annotate(family="mlp", kernel=_a2_kernel_name(kp, B, S),
                       flops=2.0 * B * S * kq * self.macs_a2,
                       bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
@@ -485,7 +495,7 @@ class FusedUpconvHoisted:
         B, S, _ = xyz2.shape
         N, K = xyz1.shape[1], idx.shape[2]
         pooled = torch.empty((B, S, 64), dtype=torch.float32, device=xyz2.device)
-        _lib.annotate(family="mlp", kernel="upconv_h_kernel<8, 1, 16>", flops=2.0 * B * S * K * (self.macs - 64 * 128),
+        _lib.annotate(family="mlp", kernel=_kname("upconv_h_kernel<8, 1, 16>"), flops=2.0 * B * S * K * (self.macs - 64 * 128),
                       bytes=4.0 * B * (S * K * (1 + 3 + 128) + 3 * S + 64 * S))
         _lib.call("upconv_fused_h_kernel_wrapper", xyz2.device, B, N, S, K, _p(xyz2), _p(xyz1), _p(pre),
                   _p(idx), _p(self.packed), _p(pooled))
@@ -539,15 +549,13 @@ class FusedCostVolumeHoisted:
             idx_q = knn(kq, xyz2, xyz1)
         kp = cv_pix_slots(kq)
         pix = torch.empty((B, S * kp, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel="cv_a1_h_kernel<%d, 1, 16>" % kp,
+        _lib.annotate(family="mlp", kernel=_kname("cv_a1_h_kernel<%d, 1, 16>" % kp),
                       flops=2.0 * B * S * kq * (self.macs_a1 - 2 * c * 128),
                       bytes=4.0 * B * (S * kq * (1 + 3 + 128 + 64) + S * (3 + 128)))
         _lib.call("cv_fused_a1_h_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(u), _p(xyz2), _p(v), _p(idx_q),
                   _p(self.w_a1), _p(pix))
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel={32: "cv_a2_kernel<32, 2, 8>", 16: "cv_a2_kernel<16, 1, 16>", 8: "cv_a2_kernel<8, 1, 16>",
-                                            6: "cv_a2_dense6_kernel<8>" if B * ((S + 7) // 8) > 2048
-                                            else "cv_a2_dense6_kernel<4>"}[kp],
+        _lib.annotate(family="mlp", kernel=_a2_kernel_name(kp, B, S),
                       flops=2.0 * B * S * kq * self.macs_a2,
                       bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
@@ -556,7 +564,7 @@ class FusedCostVolumeHoisted:
             idx = knn(k, xyz1, xyz1)
         (v2,) = run_linear_jobs([(self.job_v2, first)])
         out = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel="cv_b_h_kernel<4, 1, %d>" % (4 if B * ((S * 4 + 15) // 16) <= 2048 else 16),
+        _lib.annotate(family="mlp", kernel=_kname("cv_b_h_kernel<4, 1, %d>" % (4 if B * ((S * 4 + 15) // 16) <= 2048 else 16)),
                       flops=2.0 * B * S * k * (self.macs_b - (c + 64) * 128),
                       bytes=4.0 * B * (S * k * (1 + 3 + 128 + 64) + S * (3 + 128 + 64)))
         _lib.call("cv_fused_b_h_kernel_wrapper", dev, B, S, k, _p(xyz1), _p(u2), _p(v2), _p(first), _p(idx),
