@@ -215,3 +215,27 @@ def test_prediction_module_adapter_contract():
     assert len(keys) == 510 and all(k.startswith("pwclonet.") for k in keys)
     with pytest.raises(RuntimeError, match="CPU not supported"):       # no CPU path in the product
         mod.eval()([a, b])
+
+
+def test_pointnet2_ops_package_name_and_setup():
+    """SURVEY section 8b "package / build": the names the reference imports (pointnet2_ops, pointnet2_ops._ext,
+    pointnet2_ops.pointnet2_utils ...; P2/__init__.py:1-3, pointnet2_utils.py:7-9) resolve to this implementation's
+    modules themselves, the nine pybind names exist, and setup.py declares the same distribution name."""
+    import subprocess
+    import sys
+    import pointnet2_ops
+    import pointnet2_ops._ext as ext
+    import pointnet2_ops.pointnet2_modules as mods
+    from pointnet2_ops import pointnet2_utils, pytorch_utils
+    import pwclonet_pylidarslam_amd.pointnet2_ops as ours
+    assert ext is ours._ext and pointnet2_utils is ours.pointnet2_utils
+    assert mods is ours.pointnet2_modules and pytorch_utils is ours.pytorch_utils
+    assert pointnet2_utils._ext is ext
+    for name in ("gather_points", "gather_points_grad", "furthest_point_sampling", "three_nn", "three_interpolate",
+                 "three_interpolate_grad", "ball_query", "group_points", "group_points_grad"):   # bindings.cpp:6-19
+        assert callable(getattr(ext, name)), name
+    assert hasattr(mods, "PointnetSAModulePWCLONet") and hasattr(mods, "PointnetFPModulePWCLONet")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    out = subprocess.run([sys.executable, "setup.py", "--name", "--version"], cwd=root, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[-2:] == ["pointnet2_ops", pointnet2_ops.__version__]
