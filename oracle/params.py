@@ -53,3 +53,33 @@ def make_state_dict(shapes):
     for k, shp in shapes.items():
         out[k] = torch.from_numpy(np.array(fill_value(k, tuple(shp)))).reshape(tuple(shp))
     return out
+
+
+def fill_generic(key, shape):
+    """Closed-form fill for modules whose keys do not follow the SharedMLP naming (plain ``nn.Sequential`` of
+    Conv2d / BatchNorm2d / Linear, e.g. ``mlps.0.1.running_var``): decided by suffix and rank only."""
+    r = _rng("generic:" + key)
+    shape = tuple(shape)
+    if key.endswith("num_batches_tracked"):
+        return np.asarray(0, dtype=np.int64)
+    if key.endswith("running_mean"):
+        return r.uniform(-0.2, 0.2, shape).astype(np.float32)
+    if key.endswith("running_var"):
+        return r.uniform(0.6, 1.4, shape).astype(np.float32)
+    if len(shape) >= 2:
+        fan_out, fan_in = shape[0], int(np.prod(shape[1:]))
+        a = float(np.sqrt(6.0 / (fan_in + fan_out)))
+        return r.uniform(-a, a, shape).astype(np.float32)
+    if key.endswith("weight"):
+        return r.uniform(0.8, 1.2, shape).astype(np.float32)
+    if key.endswith("bias"):
+        return r.uniform(-0.1, 0.1, shape).astype(np.float32)
+    raise KeyError(f"params.fill_generic: unexpected state_dict key {key!r}")
+
+
+def fill_module_generic(module):
+    """In-place ``fill_generic`` of every entry of ``module.state_dict()``.  Returns the module."""
+    with torch.no_grad():
+        for k, v in module.state_dict().items():
+            v.copy_(torch.from_numpy(np.array(fill_generic(k, v.shape))).reshape(v.shape).to(v.dtype))
+    return module

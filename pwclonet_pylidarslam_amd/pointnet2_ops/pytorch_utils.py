@@ -10,6 +10,13 @@ import torch.nn as nn
 from . import _ext
 
 
+def _nn_distance(pc1, pc2):
+    """pytorch_utils.py:12-29: dense (B,N1,N2) matrix of ``sqrt(|p - q|^2 + 1e-8)``.  Kept for callers of the
+    package; ``knn_point`` below does not materialise it."""
+    diff = pc1.unsqueeze(2) - pc2.unsqueeze(1)
+    return torch.sqrt(torch.sum(diff ** 2, dim=-1) + 1e-8)
+
+
 def knn_point(nsample, xyz, new_xyz):
     """(nsample, xyz (B,N,3), new_xyz (B,S,3)) -> (group_idx, group_idx) with group_idx
     (B,S,nsample) int32, ascending distance.  The reference returns the index tensor in both
@@ -23,21 +30,26 @@ class _BN(nn.Sequential):
     """pytorch_utils.py:86-111: a Sequential holding one BatchNorm under the name ``bn``
     (weight 1, bias 0), so parameters appear as ``...bn.bn.weight``."""
 
-    def __init__(self, in_size, batch_norm):
+    def __init__(self, in_size, batch_norm, name=""):
         super().__init__()
-        self.add_module("bn", batch_norm(in_size))
+        self.add_module(name + "bn", batch_norm(in_size))
         nn.init.constant_(self[0].weight, 1.0)
         nn.init.constant_(self[0].bias, 0)
 
 
 class BatchNorm1d(_BN):
     def __init__(self, in_size: int, *, name: str = ""):
-        super().__init__(in_size, nn.BatchNorm1d)
+        super().__init__(in_size, nn.BatchNorm1d, name)
 
 
 class BatchNorm2d(_BN):
     def __init__(self, in_size: int, name: str = ""):
-        super().__init__(in_size, nn.BatchNorm2d)
+        super().__init__(in_size, nn.BatchNorm2d, name)
+
+
+class BatchNorm3d(_BN):
+    def __init__(self, in_size: int, name: str = ""):
+        super().__init__(in_size, nn.BatchNorm3d, name)
 
 
 class _ConvBlock(nn.Sequential):
@@ -45,7 +57,7 @@ class _ConvBlock(nn.Sequential):
     there is no batch norm; modules are registered as ``conv`` / ``bn`` / ``activation``."""
 
     def __init__(self, conv_cls, bn_cls, in_size, out_size, kernel_size, stride, padding, activation,
-                 bn, init, bias, preact):
+                 bn, init, bias, preact, name=""):
         super().__init__()
         bias = bias and (not bn)
         conv = conv_cls(in_size, out_size, kernel_size=kernel_size, stride=stride, padding=padding,
@@ -55,15 +67,15 @@ class _ConvBlock(nn.Sequential):
             nn.init.constant_(conv.bias, 0)
         if preact:
             if bn:
-                self.add_module("bn", bn_cls(in_size))
+                self.add_module(name + "bn", bn_cls(in_size))
             if activation is not None:
-                self.add_module("activation", activation)
-        self.add_module("conv", conv)
+                self.add_module(name + "activation", activation)
+        self.add_module(name + "conv", conv)
         if not preact:
             if bn:
-                self.add_module("bn", bn_cls(out_size))
+                self.add_module(name + "bn", bn_cls(out_size))
             if activation is not None:
-                self.add_module("activation", activation)
+                self.add_module(name + "activation", activation)
 
 
 class Conv1d(_ConvBlock):
@@ -71,7 +83,7 @@ class Conv1d(_ConvBlock):
                  padding=0, activation=nn.ReLU(inplace=True), bn: bool = False,
                  init=nn.init.kaiming_normal_, bias: bool = True, preact: bool = False, name: str = ""):
         super().__init__(nn.Conv1d, BatchNorm1d, in_size, out_size, kernel_size, stride, padding,
-                         activation, bn, init, bias, preact)
+                         activation, bn, init, bias, preact, name)
 
 
 class Conv2d(_ConvBlock):
@@ -80,7 +92,40 @@ class Conv2d(_ConvBlock):
                  bn: bool = False, init=nn.init.kaiming_normal_, bias: bool = True,
                  preact: bool = False, name: str = ""):
         super().__init__(nn.Conv2d, BatchNorm2d, in_size, out_size, kernel_size, stride, padding,
-                         activation, bn, init, bias, preact)
+                         activation, bn, init, bias, preact, name)
+
+
+class Conv3d(_ConvBlock):
+    def __init__(self, in_size: int, out_size: int, *, kernel_size: Tuple[int, int, int] = (1, 1, 1),
+                 stride: Tuple[int, int, int] = (1, 1, 1), padding=(0, 0, 0), activation=nn.ReLU(inplace=True),
+                 bn: bool = False, init=nn.init.kaiming_normal_, bias: bool = True,
+                 preact: bool = False, name: str = ""):
+        super().__init__(nn.Conv3d, BatchNorm3d, in_size, out_size, kernel_size, stride, padding,
+                         activation, bn, init, bias, preact, name)
+
+
+class FC(nn.Sequential):
+    """pytorch_utils.py:272-307: [bn, act,] Linear [, bn, act]; the Linear has a bias only without batch norm."""
+
+    def __init__(self, in_size: int, out_size: int, *, activation=nn.ReLU(inplace=True), bn: bool = False,
+                 init=None, preact: bool = False, name: str = ""):
+        super().__init__()
+        fc = nn.Linear(in_size, out_size, bias=not bn)
+        if init is not None:
+            init(fc.weight)
+        if not bn:
+            nn.init.constant_(fc.bias, 0)
+        if preact:
+            if bn:
+                self.add_module(name + "bn", BatchNorm1d(in_size))
+            if activation is not None:
+                self.add_module(name + "activation", activation)
+        self.add_module(name + "fc", fc)
+        if not preact:
+            if bn:
+                self.add_module(name + "bn", BatchNorm1d(out_size))
+            if activation is not None:
+                self.add_module(name + "activation", activation)
 
 
 class SharedMLP(nn.Sequential):
