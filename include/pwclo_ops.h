@@ -251,6 +251,22 @@ void kitti360_filter_kernel_wrapper(int n, float ground_z, float near, const flo
 void compact_frames_kernel_wrapper(int b, int n, int cap, const int *keep, const int *pos, const float *xyz,
                                    float *out, int *counts);
 
+/* Training-mode BatchNorm over x (b, c, l) f32 (l = product of the trailing dimensions), the statistics pass of
+ * the module path's Conv -> BN -> ReLU stacks (P2/pytorch_utils.py:86-111 wraps torch.nn.BatchNorm{1,2}d; semantics
+ * of torch.nn.functional.batch_norm(training=True)): y = (x - mean) * invstd * gamma + beta with the batch's
+ * mean / biased variance per channel, running_* updated in place with `momentum` and the unbiased variance
+ * (both may be NULL), save_mean / save_invstd (c) kept for the backward.  gamma / beta may be NULL (1 / 0).
+ * workspace: batchnorm_train_workspace_bytes(c) bytes of device memory, 8-byte aligned. */
+long long batchnorm_train_workspace_bytes(int c);
+void batchnorm_train_forward_kernel_wrapper(int b, int c, int l, const float *x, const float *gamma,
+                                            const float *beta, float eps, float momentum, float *running_mean,
+                                            float *running_var, float *y, float *save_mean, float *save_invstd,
+                                            void *workspace);
+/* dx (b, c, l), dgamma (c), dbeta (c) from dy and the saved statistics. */
+void batchnorm_train_backward_kernel_wrapper(int b, int c, int l, const float *x, const float *dy,
+                                             const float *gamma, const float *save_mean, const float *save_invstd,
+                                             float *dx, float *dgamma, float *dbeta, void *workspace);
+
 /* ---- 4. hoisted variants of section 3 ----------------------------------------------------------
  * The first layer of every grouped MLP is linear in [geometry | feat_centre[s] | feat_nbr[n]]; the
  * feature parts depend on one point only, so W_feat . feat[point] (+ bias) is computed once per

@@ -45,6 +45,10 @@ SIGNATURES = {
     "kitti_transform_filter_kernel_wrapper": ([_i, _F, _F, _F, _F], None),
     "kitti360_filter_kernel_wrapper": ([_i, ctypes.c_float, ctypes.c_float, _F, _F, _F], None),
     "compact_frames_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F, _F], None),
+    "batchnorm_train_workspace_bytes": ([_i], ctypes.c_longlong),
+    "batchnorm_train_forward_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, ctypes.c_float, ctypes.c_float, _F, _F, _F, _F,
+                                                _F, _F], None),
+    "batchnorm_train_backward_kernel_wrapper": ([_i, _i, _i] + [_F] * 9, None),
     "group_points_grad_sorted_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, _F, _F, _F], None),
     "upconv_fused_kernel_wrapper": ([_i] * 4 + [_F] * 6, None),
     "pointwise_fused_kernel_wrapper": ([_i] * 7 + [_F] * 5, None),

@@ -1,0 +1,69 @@
+"""Training-mode BatchNorm on the HIP kernels of ``csrc/batchnorm.hip``.
+
+``batch_norm_train`` has the semantics of ``torch.nn.functional.batch_norm(..., training=True)`` for float32
+``(B, C, *)`` CUDA/HIP tensors and is what the ``BatchNorm1d/2d`` wrappers of ``pointnet2_ops.pytorch_utils`` call
+in training mode: the module path's activations are ``(B, C, S, K)`` with few channels and very long rows, a shape
+the stock kernels run an order of magnitude below the HBM rate.  Evaluation mode is untouched (plain torch, and
+folded into the packed weights on the fused path).
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+
+def _workspace(c, device):
+    nbytes = _lib.load().batchnorm_train_workspace_bytes(int(c))
+    return torch.empty((nbytes // 8,), dtype=torch.float64, device=device)
+
+
+class _BatchNormTrain(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        if not x.is_cuda:
+            raise RuntimeError("CPU not supported")
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = _workspace(C, x.device)
+        p = lambda t: t.data_ptr() if t is not None else 0
+        _lib.call("batchnorm_train_forward_kernel_wrapper", x.device, B, C, L, p(x), p(weight), p(bias), float(eps),
+                  float(momentum), p(running_mean), p(running_var), p(y), p(save_mean), p(save_invstd), p(ws))
+        ctx.save_for_backward(x, weight, save_mean, save_invstd)
+        ctx.mark_non_differentiable(save_mean, save_invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, save_mean, save_invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = _workspace(C, x.device)
+        p = lambda t: t.data_ptr() if t is not None else 0
+        _lib.call("batchnorm_train_backward_kernel_wrapper", x.device, B, C, L, p(x), p(dy), p(weight), p(save_mean),
+                  p(save_invstd), p(dx), p(dgamma), p(dbeta), p(ws))
+        return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), None, None, None, None
+
+
+def supported(x, bn):
+    """The custom path covers what the PWCLO-Net stacks use; anything else stays on torch."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and x.numel() > 0 and bn.momentum is not None
+            and (bn.weight is None) == (bn.bias is None)
+            and (not bn.track_running_stats or bn.running_mean is not None))
+
+
+def batch_norm_train(x, bn):
+    """Training-mode forward of the ``torch.nn.BatchNorm*`` module ``bn`` on ``x`` (updates its running statistics
+    and ``num_batches_tracked`` like ``bn(x)`` does)."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)

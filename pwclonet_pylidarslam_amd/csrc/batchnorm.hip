@@ -1,0 +1,259 @@
+// Training-mode BatchNorm over (B, C, L) / (B, C, S, K) activations for gfx950.
+//
+// The module path of PWCLO-Net normalises (B, C, S, K) tensors with FEW channels and very long rows
+// (set abstraction level 1: C = 8..16, S*K = 65 536 per cloud).  The stock kernels assign their
+// parallelism per channel and run those shapes an order of magnitude below the HBM rate (measured: 2.5 ms
+// forward for a 268 MB tensor with C = 16).  Here every pass is a grid over (position range, channel):
+//   forward   stats:  per-(channel, range) partial sum / sum of squares in fp64  -> workspace
+//             finish: mean, biased variance, 1/sqrt(var+eps), running statistics (momentum, unbiased variance)
+//             apply:  y = (x - mean) * invstd * gamma + beta
+//   backward  reduce: partial sum(dy), sum(dy * xhat) in fp64                      -> workspace
+//             finish: dgamma, dbeta
+//             apply:  dx = gamma * invstd * (dy - dbeta/M - xhat * dgamma/M)
+// HBM-bound: 3 passes forward (2 reads + 1 write), 5 backward; fp64 accumulation keeps the statistics
+// independent of the split and within fp32 rounding of a two-pass evaluation.
+#include <math.h>
+#include <stdint.h>
+
+#include "common.hpp"
+
+namespace pwclo {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_SPLITS = 256;
+
+__device__ __forceinline__ double bn_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Sum of (a, b) over the workgroup; valid in thread 0.
+__device__ __forceinline__ void bn_block_sum2(double &a, double &b) {
+  __shared__ double red[2][BN_THREADS / 64];
+  a = bn_wave_sum(a);
+  b = bn_wave_sum(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = 0.0; b = 0.0;
+#pragma unroll
+    for (int w = 0; w < BN_THREADS / 64; ++w) { a += red[0][w]; b += red[1][w]; }
+  }
+}
+
+// One workgroup: channel blockIdx.y, flat positions [blockIdx.x*per_split, +per_split) of the B*L elements of
+// that channel (position f = b*L + l).  MODE 0: (sum x, sum x^2).  MODE 1: (sum dy, sum dy*xhat).
+template <int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(int C, int L, long long M, long long per_split,
+                                                                const float *__restrict__ x,
+                                                                const float *__restrict__ dy,
+                                                                const float *__restrict__ mean,
+                                                                const float *__restrict__ invstd,
+                                                                double *__restrict__ partial) {
+  const int ch = blockIdx.y;
+  const long long f0 = (long long)blockIdx.x * per_split;
+  const long long f1 = f0 + per_split < M ? f0 + per_split : M;
+  const float mu = MODE == 1 ? mean[ch] : 0.f, is = MODE == 1 ? invstd[ch] : 0.f;
+  double s0 = 0.0, s1 = 0.0;
+  const bool vec = (L % 4 == 0);           // per_split is a multiple of 4: a float4 never straddles a row
+  const int step = vec ? BN_THREADS * 4 : BN_THREADS;
+  long long f = f0 + (long long)threadIdx.x * (vec ? 4 : 1);
+  int b = (int)(f / L);                    // one division per thread; (b, l) advance incrementally below
+  int l = (int)(f - (long long)b * L);
+  for (; f < f1; f += step) {
+    const size_t off = ((size_t)b * C + ch) * (size_t)L + l;
+    if (vec) {
+      const float4 v = *reinterpret_cast<const float4 *>(x + off);
+      if (MODE == 0) {
+        s0 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        s1 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+      } else {
+        const float4 g = *reinterpret_cast<const float4 *>(dy + off);
+        s0 += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
+        s1 += ((double)g.x * ((v.x - mu) * is) + (double)g.y * ((v.y - mu) * is)) +
+              ((double)g.z * ((v.z - mu) * is) + (double)g.w * ((v.w - mu) * is));
+      }
+    } else {
+      const float v = x[off];
+      if (MODE == 0) {
+        s0 += (double)v;
+        s1 += (double)v * v;
+      } else {
+        const float g = dy[off];
+        s0 += (double)g;
+        s1 += (double)g * ((v - mu) * is);
+      }
+    }
+    l += step;
+    while (l >= L) { l -= L; ++b; }
+  }
+  bn_block_sum2(s0, s1);
+  if (threadIdx.x == 0) {
+    partial[((size_t)ch * gridDim.x + blockIdx.x) * 2 + 0] = s0;
+    partial[((size_t)ch * gridDim.x + blockIdx.x) * 2 + 1] = s1;
+  }
+}
+
+// One thread per channel: fold the partials.
+__global__ void bn_forward_finish_kernel(int C, int nsplit, long long M, float eps, float momentum,
+                                         const double *__restrict__ partial, float *__restrict__ running_mean,
+                                         float *__restrict__ running_var, float *__restrict__ save_mean,
+                                         float *__restrict__ save_invstd) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    s0 += partial[((size_t)ch * nsplit + s) * 2 + 0];
+    s1 += partial[((size_t)ch * nsplit + s) * 2 + 1];
+  }
+  const double mean = s0 / (double)M;
+  double var = s1 / (double)M - mean * mean;     // fp64: no visible cancellation for fp32 data
+  if (var < 0.0) var = 0.0;
+  save_mean[ch] = (float)mean;
+  save_invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[ch] = (float)((1.0 - (double)momentum) * (double)running_mean[ch] + (double)momentum * mean);
+    running_var[ch] = (float)((1.0 - (double)momentum) * (double)running_var[ch] + (double)momentum * unbiased);
+  }
+}
+
+__global__ void bn_backward_finish_kernel(int C, int nsplit, const double *__restrict__ partial,
+                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    s0 += partial[((size_t)ch * nsplit + s) * 2 + 0];
+    s1 += partial[((size_t)ch * nsplit + s) * 2 + 1];
+  }
+  dbeta[ch] = (float)s0;
+  dgamma[ch] = (float)s1;
+}
+
+// Element-wise passes: grid (ceil(L / (4*BN_THREADS)) or ceil(L / BN_THREADS), C, B).
+// MODE 0: y = (x - mean) * invstd * gamma + beta.   MODE 1: dx (see header).
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, float inv_m,
+                                                              const float *__restrict__ x,
+                                                              const float *__restrict__ dy,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta,
+                                                              const float *__restrict__ mean,
+                                                              const float *__restrict__ invstd,
+                                                              const float *__restrict__ dgamma,
+                                                              const float *__restrict__ dbeta,
+                                                              float *__restrict__ out) {
+  const int ch = blockIdx.y, b = blockIdx.z;
+  const size_t row = ((size_t)b * C + ch) * (size_t)L;
+  const float mu = mean[ch], is = invstd[ch];
+  const float g = gamma != nullptr ? gamma[ch] : 1.f;
+  float c0 = 0.f, c1 = 0.f;
+  if (MODE == 0) {
+    c0 = beta != nullptr ? beta[ch] : 0.f;
+  } else {
+    c0 = dbeta[ch] * inv_m;
+    c1 = dgamma[ch] * inv_m;
+  }
+  auto f = [&](float xv, float gv) -> float {
+    const float xh = (xv - mu) * is;
+    if (MODE == 0) return xh * g + c0;
+    return ((gv - c0) - xh * c1) * (g * is);
+  };
+  if (VEC) {
+    const int l = (blockIdx.x * BN_THREADS + threadIdx.x) * 4;
+    if (l >= L) return;
+    const float4 xv = *reinterpret_cast<const float4 *>(x + row + l);
+    float4 gv = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) gv = *reinterpret_cast<const float4 *>(dy + row + l);
+    float4 o;
+    o.x = f(xv.x, gv.x); o.y = f(xv.y, gv.y); o.z = f(xv.z, gv.z); o.w = f(xv.w, gv.w);
+    *reinterpret_cast<float4 *>(out + row + l) = o;
+  } else {
+    const int l = blockIdx.x * BN_THREADS + threadIdx.x;
+    if (l >= L) return;
+    out[row + l] = f(x[row + l], MODE == 1 ? dy[row + l] : 0.f);
+  }
+}
+
+static int bn_splits(int c, long long M, long long *per_split) {
+  long long want = 2048 / (c > 0 ? c : 1);                       // ~2048 workgroups in the reduction passes
+  if (want < 1) want = 1;
+  if (want > BN_MAX_SPLITS) want = BN_MAX_SPLITS;
+  long long ps = (M + want - 1) / want;
+  const long long min_ps = 4ll * BN_THREADS * 4;                 // at least 4 float4 per thread
+  if (ps < min_ps) ps = min_ps;
+  ps = (ps + 3) / 4 * 4;
+  *per_split = ps;
+  return (int)((M + ps - 1) / ps);
+}
+
+}  // namespace pwclo
+
+using namespace pwclo;
+
+extern "C" long long batchnorm_train_workspace_bytes(int c) {
+  return (long long)(c > 0 ? c : 1) * BN_MAX_SPLITS * 2 * (long long)sizeof(double);
+}
+
+extern "C" void batchnorm_train_forward_kernel_wrapper(int b, int c, int l, const float *x, const float *gamma,
+                                                       const float *beta, float eps, float momentum,
+                                                       float *running_mean, float *running_var, float *y,
+                                                       float *save_mean, float *save_invstd, void *workspace) {
+  if (b <= 0 || c <= 0 || l <= 0) return;
+  PWCLO_REQUIRE(b <= 65535 && c <= 65535, "batchnorm_train_forward: b=%d c=%d exceed the grid limits", b, c);
+  PWCLO_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+                "batchnorm_train_forward: running_mean and running_var must be given together%s", "");
+  PWCLO_REQUIRE(l % 4 != 0 || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0),
+                "batchnorm_train_forward: x and y must be 16-byte aligned%s", "");
+  const long long M = (long long)b * l;
+  long long per_split;
+  const int nsplit = bn_splits(c, M, &per_split);
+  double *partial = reinterpret_cast<double *>(workspace);
+  hipStream_t st = current_stream();
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x,
+                     (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, partial);
+  hipLaunchKernelGGL(bn_forward_finish_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, st, c, nsplit, M, eps, momentum,
+                     partial, running_mean, running_var, save_mean, save_invstd);
+  const bool vec = (l % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL((bn_apply_kernel<0, true>), dim3(ceil_div(l, 4 * BN_THREADS), c, b), dim3(BN_THREADS), 0, st, c,
+                       l, 0.f, x, (const float *)nullptr, gamma, beta, save_mean, save_invstd,
+                       (const float *)nullptr, (const float *)nullptr, y);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<0, false>), dim3(ceil_div(l, BN_THREADS), c, b), dim3(BN_THREADS), 0, st, c,
+                       l, 0.f, x, (const float *)nullptr, gamma, beta, save_mean, save_invstd,
+                       (const float *)nullptr, (const float *)nullptr, y);
+  check_launch("batchnorm_train_forward");
+}
+
+extern "C" void batchnorm_train_backward_kernel_wrapper(int b, int c, int l, const float *x, const float *dy,
+                                                        const float *gamma, const float *save_mean,
+                                                        const float *save_invstd, float *dx, float *dgamma,
+                                                        float *dbeta, void *workspace) {
+  if (b <= 0 || c <= 0 || l <= 0) return;
+  PWCLO_REQUIRE(b <= 65535 && c <= 65535, "batchnorm_train_backward: b=%d c=%d exceed the grid limits", b, c);
+  const long long M = (long long)b * l;
+  long long per_split;
+  const int nsplit = bn_splits(c, M, &per_split);
+  double *partial = reinterpret_cast<double *>(workspace);
+  hipStream_t st = current_stream();
+  const bool vec = (l % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0);
+  PWCLO_REQUIRE(l % 4 != 0 || vec, "batchnorm_train_backward: x, dy and dx must be 16-byte aligned%s", "");
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x, dy,
+                     save_mean, save_invstd, partial);
+  hipLaunchKernelGGL(bn_backward_finish_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, st, c, nsplit, partial, dgamma,
+                     dbeta);
+  const float inv_m = (float)(1.0 / (double)M);
+  if (vec)
+    hipLaunchKernelGGL((bn_apply_kernel<1, true>), dim3(ceil_div(l, 4 * BN_THREADS), c, b), dim3(BN_THREADS), 0, st, c,
+                       l, inv_m, x, dy, gamma, (const float *)nullptr, save_mean, save_invstd, dgamma, dbeta, dx);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<1, false>), dim3(ceil_div(l, BN_THREADS), c, b), dim3(BN_THREADS), 0, st, c,
+                       l, inv_m, x, dy, gamma, (const float *)nullptr, save_mean, save_invstd, dgamma, dbeta, dx);
+  check_launch("batchnorm_train_backward");
+}

@@ -128,6 +128,67 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(
     atomicAdd(grad_points + ((size_t)b * c + l) * n + ii, grad_out[((size_t)b * c + l) * P + p]);
 }
 
+// Same sums through LDS: a workgroup owns (cloud b, a slice of CT channels, a contiguous range of positions
+// p), keeps the slice's CT x n accumulators in LDS (ds_add_f32, no return), and adds its non-zero totals to
+// grad_points once at the end -- S*K*C global fp32 atomics (two dozen G/s on contended rows) become LDS
+// atomics plus one plain read-modify-write of the slice (or, when the positions of a slice are split over
+// several workgroups, at most n*CT global atomics per workgroup).  idx is read once per position and reused for the CT
+// channels; grad_out rows are read coalesced.  CT*n*4 <= 128 KiB (host picks CT), `splits` ranges of p per
+// (b, slice) keep > 256 workgroups in flight when b*C/CT is small.
+constexpr int GG_THREADS = 512;
+constexpr int GG_LDS_BYTES = 128 * 1024;
+
+__global__ __launch_bounds__(GG_THREADS) void group_points_grad_lds_kernel(
+    int c, int n, int P, int ct, int per_split, int vec4, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_points) {
+  extern __shared__ __attribute__((aligned(16))) float gg_acc[];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * ct;
+  const int nch = min(ct, c - c0);
+  const int total = nch * n;
+  for (int i = threadIdx.x; i < total; i += GG_THREADS) gg_acc[i] = 0.f;
+  __syncthreads();
+  const int p0 = blockIdx.x * per_split, p1 = min(P, p0 + per_split);
+  const int *ib = idx + (size_t)b * P;
+  const float *g0 = grad_out + ((size_t)b * c + c0) * P;
+  auto add = [&](int l, int ii, float v) {
+    __hip_atomic_fetch_add(gg_acc + l * n + ii, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  if (vec4) {     // P % 4 == 0, per_split % 4 == 0, 16-byte aligned rows: all loads of a step in flight together
+    for (int p = p0 + threadIdx.x * 4; p < p1; p += GG_THREADS * 4) {
+      const int4 ii = *reinterpret_cast<const int4 *>(ib + p);
+      float4 g[GP_CH_PER_BLOCK];
+#pragma unroll
+      for (int l = 0; l < GP_CH_PER_BLOCK; ++l)
+        if (l < nch) g[l] = *reinterpret_cast<const float4 *>(g0 + (size_t)l * P + p);
+#pragma unroll
+      for (int l = 0; l < GP_CH_PER_BLOCK; ++l)
+        if (l < nch) { add(l, ii.x, g[l].x); add(l, ii.y, g[l].y); add(l, ii.z, g[l].z); add(l, ii.w, g[l].w); }
+    }
+  } else {
+    for (int p = p0 + threadIdx.x; p < p1; p += GG_THREADS) {
+      const int ii = ib[p];
+      float g[GP_CH_PER_BLOCK];
+#pragma unroll
+      for (int l = 0; l < GP_CH_PER_BLOCK; ++l)
+        if (l < nch) g[l] = g0[(size_t)l * P + p];
+#pragma unroll
+      for (int l = 0; l < GP_CH_PER_BLOCK; ++l)
+        if (l < nch) add(l, ii, g[l]);
+    }
+  }
+  __syncthreads();
+  float *o = grad_points + ((size_t)b * c + c0) * n;
+  if (gridDim.x == 1) {   // sole owner of these rows: plain read-modify-write (global fp32 atomics run at ~24 G/s)
+    for (int i = threadIdx.x; i < total; i += GG_THREADS) o[i] += gg_acc[i];
+    return;
+  }
+  for (int i = threadIdx.x; i < total; i += GG_THREADS) {
+    const float v = gg_acc[i];
+    if (v != 0.f) atomicAdd(o + i, v);     // += like the reference (caller zero-fills)
+  }
+}
+
 // Atomics-free, run-to-run deterministic scatter-add: the (b, p) -> n map is
 // inverted on the host side of the C ABI (a stable sort of idx per cloud: `perm` lists the p of every
 // source point n contiguously and in ascending p, `seg` holds the n+1 segment boundaries); one thread
@@ -217,6 +278,30 @@ extern "C" void group_points_grad_kernel_wrapper(int b, int c, int n, int npoint
   PWCLO_REQUIRE(P64 < (1ll << 31) && b <= 65535,
                 "group_points_grad: npoints*nsample=%lld or b=%d too large", P64, b);
   const int P = (int)P64;
+  static int use_lds = -1;
+  if (use_lds < 0) { const char *e = getenv("PWCLO_GRAD_LDS"); use_lds = e ? atoi(e) : 1; }
+  if (use_lds && (long long)n * 4 <= GG_LDS_BYTES) {
+    int ct = 8;
+    while ((long long)ct * n * 4 > GG_LDS_BYTES) ct >>= 1;
+    if (ct > c) ct = c;
+    while (ct > 1 && b * ceil_div(c, ct) < 256) ct >>= 1;        // narrower slices before splitting positions
+    const int slices = ceil_div(c, ct);
+    int splits = b * slices >= 64 ? 1 : ceil_div(256, b * slices);   // split ranges flush with global atomics
+    splits = max(1, min(splits, ceil_div(P, 4 * GG_THREADS)));
+    const int per_split = ceil_div(ceil_div(P, splits), 4) * 4;
+    const int vec4 = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_out) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(idx) & 15) == 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void *)group_points_grad_lds_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GG_LDS_BYTES);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(group_points_grad_lds_kernel, dim3(ceil_div(P, per_split), slices, b), dim3(GG_THREADS),
+                       (size_t)ct * n * 4, current_stream(), c, n, P, ct, per_split, vec4, grad_out, idx, grad_points);
+    check_launch("group_points_grad");
+    return;
+  }
   hipLaunchKernelGGL(group_points_grad_kernel, dim3(ceil_div(P, GP_THREADS), ceil_div(c, GP_CH_PER_BLOCK), b),
                      dim3(GP_THREADS), 0, current_stream(), c, n, P, grad_out, idx, grad_points);
   check_launch("group_points_grad");

@@ -97,6 +97,55 @@ __global__ __launch_bounds__(TI_THREADS) void three_interpolate_grad_kernel(
   }
 }
 
+// The same sums through LDS (see group_points_grad_lds_kernel): a workgroup owns (cloud, CT channels, a range
+// of the n fine points), accumulates w_j * grad_out into CT x m LDS accumulators and adds its non-zero totals
+// to grad_points once.
+constexpr int TG_THREADS = 512;
+constexpr int TG_LDS_BYTES = 128 * 1024;
+
+__global__ __launch_bounds__(TG_THREADS) void three_interpolate_grad_lds_kernel(
+    int c, int n, int m, int ct, int per_split, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, const float *__restrict__ weight, float *__restrict__ grad_points) {
+  extern __shared__ __attribute__((aligned(16))) float tg_acc[];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * ct;
+  const int nch = min(ct, c - c0);
+  const int total = nch * m;
+  for (int i = threadIdx.x; i < total; i += TG_THREADS) tg_acc[i] = 0.f;
+  __syncthreads();
+  const int j0 = blockIdx.x * per_split, j1 = min(n, j0 + per_split);
+  const float *g0 = grad_out + ((size_t)b * c + c0) * n;
+  for (int j = j0 + threadIdx.x; j < j1; j += TG_THREADS) {
+    const float *w = weight + ((size_t)b * n + j) * 3;
+    const int *ix = idx + ((size_t)b * n + j) * 3;
+    const float w1 = w[0], w2 = w[1], w3 = w[2];
+    const int i1 = ix[0], i2 = ix[1], i3 = ix[2];
+    float g[8];      // ct <= 8: all channel loads of a point in flight before the first LDS atomic
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      if (l < nch) g[l] = g0[(size_t)l * n + j];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      if (l < nch) {
+        float *a = tg_acc + l * m;
+        __hip_atomic_fetch_add(a + i1, g[l] * w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(a + i2, g[l] * w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(a + i3, g[l] * w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __syncthreads();
+  float *o = grad_points + ((size_t)b * c + c0) * m;
+  if (gridDim.x == 1) {   // sole owner of these rows: plain read-modify-write (global fp32 atomics run at ~24 G/s)
+    for (int i = threadIdx.x; i < total; i += TG_THREADS) o[i] += tg_acc[i];
+    return;
+  }
+  for (int i = threadIdx.x; i < total; i += TG_THREADS) {
+    const float v = tg_acc[i];
+    if (v != 0.f) atomicAdd(o + i, v);
+  }
+}
+
 }  // namespace pwclo
 
 using namespace pwclo;
@@ -125,6 +174,29 @@ extern "C" void three_interpolate_grad_kernel_wrapper(int b, int c, int n, int m
                                                       const float *weight, float *grad_points) {
   if (b <= 0 || c <= 0 || n <= 0) return;
   PWCLO_REQUIRE(b <= 65535, "three_interpolate_grad: b=%d exceeds the grid limit", b);
+  static int use_lds = -1;
+  if (use_lds < 0) { const char *e = getenv("PWCLO_GRAD_LDS"); use_lds = e ? atoi(e) : 1; }
+  if (use_lds && m > 0 && (long long)m * 4 <= TG_LDS_BYTES) {
+    int ct = 8;
+    while ((long long)ct * m * 4 > TG_LDS_BYTES) ct >>= 1;
+    if (ct > c) ct = c;
+    while (ct > 1 && b * ceil_div(c, ct) < 256) ct >>= 1;
+    const int slices = ceil_div(c, ct);
+    int splits = b * slices >= 64 ? 1 : ceil_div(256, b * slices);
+    splits = max(1, min(splits, ceil_div(n, 2 * TG_THREADS)));
+    const int per_split = ceil_div(n, splits);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void *)three_interpolate_grad_lds_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS_BYTES);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(three_interpolate_grad_lds_kernel, dim3(ceil_div(n, per_split), slices, b),
+                       dim3(TG_THREADS), (size_t)ct * m * 4, current_stream(), c, n, m, ct, per_split, grad_out, idx,
+                       weight, grad_points);
+    check_launch("three_interpolate_grad");
+    return;
+  }
   hipLaunchKernelGGL(three_interpolate_grad_kernel,
                      dim3(ceil_div(n, TI_THREADS), ceil_div(c, TI_CH_PER_BLOCK), b), dim3(TI_THREADS),
                      0, current_stream(), c, n, m, grad_out, idx, weight, grad_points);

@@ -524,6 +524,9 @@ __global__ __launch_bounds__(256) void gather_points_grad_kernel(int c, int n, i
 
 using namespace pwclo;
 
+extern "C" void group_points_grad_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                                 const float *grad_out, const int *idx, float *grad_points);
+
 static void fps_dispatch(int b, int n, int m, const float *dataset, float *temp, int *idxs,
                          float *new_xyz, int *tie_out = nullptr, int tie_iters = 0,
                          const int *prefix_in = nullptr) {
@@ -622,6 +625,10 @@ extern "C" void gather_points_grad_kernel_wrapper(int b, int c, int n, int npoin
                                                   float *grad_points) {
   if (b <= 0 || c <= 0 || npoints <= 0) return;
   PWCLO_REQUIRE(c <= 65535 && b <= 65535, "gather_points_grad: b=%d c=%d exceed the grid limits", b, c);
+  if ((long long)n * 4 <= 128 * 1024) {   // same scatter-add as group_points_grad with one sample per centre
+    group_points_grad_kernel_wrapper(b, c, n, npoints, 1, grad_out, idx, grad_points);
+    return;
+  }
   hipLaunchKernelGGL(gather_points_grad_kernel, dim3(ceil_div(npoints, 256), c, b), dim3(256), 0,
                      current_stream(), c, n, npoints, grad_out, idx, grad_points);
   check_launch("gather_points_grad");

@@ -2,12 +2,16 @@
 Conv/BN/ReLU building blocks with the reference's ``state_dict`` naming
 (``<name>.layer{i}.conv.weight``, ``<name>.layer{i}.bn.bn.{weight,bias,running_mean,...}``).
 """
+import os
 from typing import List, Tuple
 
 import torch
 import torch.nn as nn
 
 from . import _ext
+from .. import batchnorm as _hip_bn
+
+_USE_HIP_BN = os.environ.get("PWCLO_HIP_BN", "1") != "0"
 
 
 def _nn_distance(pc1, pc2):
@@ -35,6 +39,14 @@ class _BN(nn.Sequential):
         self.add_module(name + "bn", batch_norm(in_size))
         nn.init.constant_(self[0].weight, 1.0)
         nn.init.constant_(self[0].bias, 0)
+
+    def forward(self, x):
+        bn = self[0]
+        # training mode: batch statistics on the HIP kernels (csrc/batchnorm.hip) -- same result as torch's, an
+        # order of magnitude faster on the few-channel (B,C,S,K) activations of the grouped MLPs
+        if bn.training and _USE_HIP_BN and _hip_bn.supported(x, bn):
+            return _hip_bn.batch_norm_train(x, bn)
+        return bn(x)
 
 
 class BatchNorm1d(_BN):

@@ -409,3 +409,57 @@ def test_deterministic_scatter_grad(cuda, b, c, n, s, k):
         assert torch.equal(feat.grad, out1)
     finally:
         PU.deterministic_grads(False)
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 300, 7), (8, 16, 2048, 32), (2, 64, 1, 5), (3, 5, 1000), (32, 128, 64, 8)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_batchnorm_train_kernels(cuda, shape, affine):
+    """training-mode BatchNorm on the HIP kernels equals a float64 evaluation of
+    torch.nn.functional.batch_norm(training=True) -- output, running statistics, num_batches_tracked, and the
+    gradients of input / weight / bias -- and is what the pytorch_utils BatchNorm wrappers run in train mode."""
+    from pwclonet_pylidarslam_amd import batchnorm as hip_bn
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pytorch_utils as PT
+    gen = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    x = (torch.randn(*shape, generator=gen) * 1.7 + 0.6)
+    go = torch.randn(*shape, generator=gen)
+    cls = torch.nn.BatchNorm2d if len(shape) == 4 else torch.nn.BatchNorm1d
+    ref = cls(C, affine=affine, momentum=0.1).double().train()
+    bn = cls(C, affine=affine, momentum=0.1).to(cuda).train()
+    with torch.no_grad():
+        for m in (ref, bn):
+            m.running_mean.copy_(torch.linspace(-0.5, 0.5, C))
+            m.running_var.copy_(torch.linspace(0.5, 1.5, C))
+            if affine:
+                m.weight.copy_(torch.linspace(0.7, 1.3, C))
+                m.bias.copy_(torch.linspace(-0.2, 0.2, C))
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(go.double())
+    xg = x.to(cuda).requires_grad_(True)
+    assert hip_bn.supported(xg, bn)
+    yg = hip_bn.batch_norm_train(xg, bn)
+    yg.backward(go.to(cuda))
+
+    def close(a, b, tol):
+        b = b.float()
+        assert (a.cpu() - b).abs().max() <= tol * max(1.0, float(b.abs().max())), float((a.cpu() - b).abs().max())
+    close(yg.detach(), yr.detach(), 2e-6)
+    close(bn.running_mean, ref.running_mean, 1e-6)
+    close(bn.running_var, ref.running_var, 1e-6)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    close(xg.grad, xr.grad, 5e-6)
+    if affine:
+        close(bn.weight.grad, ref.weight.grad, 2e-6)
+        close(bn.bias.grad, ref.bias.grad, 2e-6)
+    if len(shape) == 4 and affine:   # the wrapper module takes this path in train mode and torch's in eval mode
+        w = PT.BatchNorm2d(C).to(cuda)
+        w.load_state_dict({"bn." + k: v for k, v in bn.state_dict().items()})
+        w.train()
+        y2 = w(x.to(cuda))
+        w.eval()
+        y3 = w(x.to(cuda))
+        assert int(w[0].num_batches_tracked) == 2 and y2.shape == y3.shape
+        bn.eval()
+        ref2 = bn(x.to(cuda))             # eval with the statistics after ONE update; w has had two
+        assert not torch.equal(ref2, y3)

@@ -47,7 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--ops", default="fps,knn,group,gather,warp,ball,three")
+    ap.add_argument("--ops", default="fps,knn,group,gather,warp,ball,three,grads")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B = a.batch
@@ -101,12 +101,34 @@ def main():
             x = clouds(B, n, dev)
             q = x[:, :m].contiguous()
             us = timeit(lambda: E.ball_query(q, x, r, k), a.reps)
-            print(f"ball  M={m} N={n} K={k} r={r}: {us:9.1f} us")
+            nbytes = B * (12.0 * (m + n) + 4.0 * m * k)
+            print(f"ball  M={m} N={n} K={k} r={r}: {us:9.1f} us  {nbytes / us / 1e3:8.1f} GB/s  "
+                  f"{B * m * n / us / 1e3:8.1f} Gtest/s")
     if "three" in ops:
         for n, m in ((256, 64), (1024, 256), (2048, 1024)):
             u, kn = clouds(B, n, dev), clouds(B, m, dev, seed=7)
             us = timeit(lambda: E.three_nn(u, kn), a.reps)
-            print(f"three_nn n={n} m={m}: {us:9.1f} us")
+            print(f"three_nn n={n} m={m}: {us:9.1f} us  {B * (12.0 * (n + m) + 24.0 * n) / us / 1e3:8.1f} GB/s  "
+                  f"{B * n * m / us / 1e3:8.1f} Gdist/s")
+            c = 64
+            feats = torch.randn(B, c, m, device=dev)
+            dist2, idx = E.three_nn(u, kn)
+            w = torch.softmax(-dist2, dim=2).contiguous()
+            us = timeit(lambda: E.three_interpolate(feats, idx, w), a.reps)
+            nbytes = B * (4.0 * (c * m + c * n) + 24.0 * n)
+            print(f"three_interpolate c={c} n={n} m={m}: {us:9.1f} us  {nbytes / us / 1e3:8.1f} GB/s")
+            go = torch.randn(B, c, n, device=dev)
+            us = timeit(lambda: E.three_interpolate_grad(go, idx, w, m), a.reps)
+            print(f"three_interpolate_grad c={c} n={n} m={m}: {us:9.1f} us  {nbytes / us / 1e3:8.1f} GB/s")
+    if "grads" in ops:
+        for c, n, s, k in ((64, 1024, 2048, 8), (16, 2048, 1024, 32), (64, 256, 256, 32)):
+            idx = torch.randint(0, n, (B, s, k), device=dev, dtype=torch.int32)
+            go = torch.randn(B, c, s, k, device=dev)
+            nbytes = 4.0 * B * (s * k + c * n + c * s * k)
+            us = timeit(lambda: E.group_points_grad(go, idx, n), a.reps)
+            us2 = timeit(lambda: E.scatter_grad_deterministic(go, idx, n), a.reps)
+            print(f"group_points_grad C={c} N={n} S={s} K={k}: {us:9.1f} us  {nbytes / us / 1e3:8.1f} GB/s  "
+                  f"(deterministic incl. sort: {us2:9.1f} us)")
 
 
 if __name__ == "__main__":
