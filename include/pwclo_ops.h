@@ -258,14 +258,17 @@ void compact_frames_kernel_wrapper(int b, int n, int cap, const int *keep, const
  * (both may be NULL), save_mean / save_invstd (c) kept for the backward.  gamma / beta may be NULL (1 / 0).
  * workspace: batchnorm_train_workspace_bytes(c) bytes of device memory, 8-byte aligned. */
 long long batchnorm_train_workspace_bytes(int c);
+/* relu != 0 fuses the stack's following ReLU: y = max(., 0), and the backward masks dy where that output was 0
+ * (the mask is recomputed from x, nothing extra is saved). */
 void batchnorm_train_forward_kernel_wrapper(int b, int c, int l, const float *x, const float *gamma,
                                             const float *beta, float eps, float momentum, float *running_mean,
                                             float *running_var, float *y, float *save_mean, float *save_invstd,
-                                            void *workspace);
-/* dx (b, c, l), dgamma (c), dbeta (c) from dy and the saved statistics. */
+                                            void *workspace, int relu);
+/* dx (b, c, l), dgamma (c), dbeta (c) from dy (the gradient w.r.t. the forward's output) and the saved statistics. */
 void batchnorm_train_backward_kernel_wrapper(int b, int c, int l, const float *x, const float *dy,
-                                             const float *gamma, const float *save_mean, const float *save_invstd,
-                                             float *dx, float *dgamma, float *dbeta, void *workspace);
+                                             const float *gamma, const float *beta, const float *save_mean,
+                                             const float *save_invstd, float *dx, float *dgamma, float *dbeta,
+                                             void *workspace, int relu);
 
 /* ---- 4. hoisted variants of section 3 ----------------------------------------------------------
  * The first layer of every grouped MLP is linear in [geometry | feat_centre[s] | feat_nbr[n]]; the

@@ -47,8 +47,8 @@ SIGNATURES = {
     "compact_frames_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F, _F], None),
     "batchnorm_train_workspace_bytes": ([_i], ctypes.c_longlong),
     "batchnorm_train_forward_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, ctypes.c_float, ctypes.c_float, _F, _F, _F, _F,
-                                                _F, _F], None),
-    "batchnorm_train_backward_kernel_wrapper": ([_i, _i, _i] + [_F] * 9, None),
+                                                _F, _F, _i], None),
+    "batchnorm_train_backward_kernel_wrapper": ([_i, _i, _i] + [_F] * 10 + [_i], None),
     "group_points_grad_sorted_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, _F, _F, _F], None),
     "upconv_fused_kernel_wrapper": ([_i] * 4 + [_F] * 6, None),
     "pointwise_fused_kernel_wrapper": ([_i] * 7 + [_F] * 5, None),

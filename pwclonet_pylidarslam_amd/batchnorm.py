@@ -19,7 +19,7 @@ def _workspace(c, device):
 
 class _BatchNormTrain(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
         if not x.is_cuda:
             raise RuntimeError("CPU not supported")
         x = x.contiguous()
@@ -31,14 +31,14 @@ class _BatchNormTrain(Function):
         ws = _workspace(C, x.device)
         p = lambda t: t.data_ptr() if t is not None else 0
         _lib.call("batchnorm_train_forward_kernel_wrapper", x.device, B, C, L, p(x), p(weight), p(bias), float(eps),
-                  float(momentum), p(running_mean), p(running_var), p(y), p(save_mean), p(save_invstd), p(ws))
-        ctx.save_for_backward(x, weight, save_mean, save_invstd)
-        ctx.mark_non_differentiable(save_mean, save_invstd)
+                  float(momentum), p(running_mean), p(running_var), p(y), p(save_mean), p(save_invstd), p(ws), int(relu))
+        ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
+        ctx.relu = bool(relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, save_mean, save_invstd = ctx.saved_tensors
+        x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         dy = dy.contiguous()
         B, C = x.shape[0], x.shape[1]
         L = x.numel() // (B * C)
@@ -47,9 +47,10 @@ class _BatchNormTrain(Function):
         dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
         ws = _workspace(C, x.device)
         p = lambda t: t.data_ptr() if t is not None else 0
-        _lib.call("batchnorm_train_backward_kernel_wrapper", x.device, B, C, L, p(x), p(dy), p(weight), p(save_mean),
-                  p(save_invstd), p(dx), p(dgamma), p(dbeta), p(ws))
-        return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), None, None, None, None
+        _lib.call("batchnorm_train_backward_kernel_wrapper", x.device, B, C, L, p(x), p(dy), p(weight), p(bias),
+                  p(save_mean), p(save_invstd), p(dx), p(dgamma), p(dbeta), p(ws), int(ctx.relu))
+        return (dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), None, None, None,
+                None, None)
 
 
 def supported(x, bn):
@@ -59,11 +60,11 @@ def supported(x, bn):
             and (not bn.track_running_stats or bn.running_mean is not None))
 
 
-def batch_norm_train(x, bn):
+def batch_norm_train(x, bn, relu=False):
     """Training-mode forward of the ``torch.nn.BatchNorm*`` module ``bn`` on ``x`` (updates its running statistics
-    and ``num_batches_tracked`` like ``bn(x)`` does)."""
+    and ``num_batches_tracked`` like ``bn(x)`` does); ``relu=True`` also applies the stack's ReLU in the same pass."""
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu)

@@ -45,17 +45,23 @@ __device__ __forceinline__ void bn_block_sum2(double &a, double &b) {
 
 // One workgroup: channel blockIdx.y, flat positions [blockIdx.x*per_split, +per_split) of the B*L elements of
 // that channel (position f = b*L + l).  MODE 0: (sum x, sum x^2).  MODE 1: (sum dy, sum dy*xhat).
-template <int MODE>
+// RELU (MODE 1): the forward applied max(., 0) after the affine map; dy is masked where that output was 0,
+// the mask recomputed from x with the forward's own expression (no saved activation, no extra pass).
+template <int MODE, bool RELU>
 __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(int C, int L, long long M, long long per_split,
                                                                 const float *__restrict__ x,
                                                                 const float *__restrict__ dy,
                                                                 const float *__restrict__ mean,
                                                                 const float *__restrict__ invstd,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta,
                                                                 double *__restrict__ partial) {
   const int ch = blockIdx.y;
   const long long f0 = (long long)blockIdx.x * per_split;
   const long long f1 = f0 + per_split < M ? f0 + per_split : M;
   const float mu = MODE == 1 ? mean[ch] : 0.f, is = MODE == 1 ? invstd[ch] : 0.f;
+  const float ga = (RELU && gamma != nullptr) ? gamma[ch] : 1.f, be = (RELU && beta != nullptr) ? beta[ch] : 0.f;
+  auto masked = [&](float g, float xh) -> float { return (!RELU || xh * ga + be > 0.f) ? g : 0.f; };
   double s0 = 0.0, s1 = 0.0;
   const bool vec = (L % 4 == 0);           // per_split is a multiple of 4: a float4 never straddles a row
   const int step = vec ? BN_THREADS * 4 : BN_THREADS;
@@ -70,10 +76,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(int C, int L, lo
         s0 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
         s1 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
       } else {
-        const float4 g = *reinterpret_cast<const float4 *>(dy + off);
+        float4 g = *reinterpret_cast<const float4 *>(dy + off);
+        const float hx = (v.x - mu) * is, hy = (v.y - mu) * is, hz = (v.z - mu) * is, hw = (v.w - mu) * is;
+        g.x = masked(g.x, hx); g.y = masked(g.y, hy); g.z = masked(g.z, hz); g.w = masked(g.w, hw);
         s0 += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
-        s1 += ((double)g.x * ((v.x - mu) * is) + (double)g.y * ((v.y - mu) * is)) +
-              ((double)g.z * ((v.z - mu) * is) + (double)g.w * ((v.w - mu) * is));
+        s1 += ((double)g.x * hx + (double)g.y * hy) + ((double)g.z * hz + (double)g.w * hw);
       }
     } else {
       const float v = x[off];
@@ -81,9 +88,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(int C, int L, lo
         s0 += (double)v;
         s1 += (double)v * v;
       } else {
-        const float g = dy[off];
+        const float xh = (v - mu) * is;
+        const float g = masked(dy[off], xh);
         s0 += (double)g;
-        s1 += (double)g * ((v - mu) * is);
+        s1 += (double)g * xh;
       }
     }
     l += step;
@@ -135,7 +143,7 @@ __global__ void bn_backward_finish_kernel(int C, int nsplit, const double *__res
 
 // Element-wise passes: grid (ceil(L / (4*BN_THREADS)) or ceil(L / BN_THREADS), C, B).
 // MODE 0: y = (x - mean) * invstd * gamma + beta.   MODE 1: dx (see header).
-template <int MODE, bool VEC>
+template <int MODE, bool VEC, bool RELU>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, float inv_m,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ dy,
@@ -150,16 +158,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, floa
   const size_t row = ((size_t)b * C + ch) * (size_t)L;
   const float mu = mean[ch], is = invstd[ch];
   const float g = gamma != nullptr ? gamma[ch] : 1.f;
+  const float be = beta != nullptr ? beta[ch] : 0.f;
   float c0 = 0.f, c1 = 0.f;
-  if (MODE == 0) {
-    c0 = beta != nullptr ? beta[ch] : 0.f;
-  } else {
+  if (MODE == 1) {
     c0 = dbeta[ch] * inv_m;
     c1 = dgamma[ch] * inv_m;
   }
   auto f = [&](float xv, float gv) -> float {
     const float xh = (xv - mu) * is;
-    if (MODE == 0) return xh * g + c0;
+    const float yv = xh * g + be;
+    if (MODE == 0) return RELU ? fmaxf(yv, 0.f) : yv;
+    if (RELU && !(yv > 0.f)) gv = 0.f;
     return ((gv - c0) - xh * c1) * (g * is);
   };
   if (VEC) {
@@ -198,62 +207,74 @@ extern "C" long long batchnorm_train_workspace_bytes(int c) {
   return (long long)(c > 0 ? c : 1) * BN_MAX_SPLITS * 2 * (long long)sizeof(double);
 }
 
+template <int MODE, bool RELU>
+static void bn_launch_apply(bool vec, int b, int c, int l, float inv_m, const float *x, const float *dy,
+                            const float *gamma, const float *beta, const float *mean, const float *invstd,
+                            const float *dgamma, const float *dbeta, float *out, hipStream_t st) {
+  if (vec)
+    hipLaunchKernelGGL((bn_apply_kernel<MODE, true, RELU>), dim3(ceil_div(l, 4 * BN_THREADS), c, b), dim3(BN_THREADS),
+                       0, st, c, l, inv_m, x, dy, gamma, beta, mean, invstd, dgamma, dbeta, out);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<MODE, false, RELU>), dim3(ceil_div(l, BN_THREADS), c, b), dim3(BN_THREADS), 0,
+                       st, c, l, inv_m, x, dy, gamma, beta, mean, invstd, dgamma, dbeta, out);
+}
+
 extern "C" void batchnorm_train_forward_kernel_wrapper(int b, int c, int l, const float *x, const float *gamma,
                                                        const float *beta, float eps, float momentum,
                                                        float *running_mean, float *running_var, float *y,
-                                                       float *save_mean, float *save_invstd, void *workspace) {
+                                                       float *save_mean, float *save_invstd, void *workspace,
+                                                       int relu) {
   if (b <= 0 || c <= 0 || l <= 0) return;
   PWCLO_REQUIRE(b <= 65535 && c <= 65535, "batchnorm_train_forward: b=%d c=%d exceed the grid limits", b, c);
   PWCLO_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
                 "batchnorm_train_forward: running_mean and running_var must be given together%s", "");
-  PWCLO_REQUIRE(l % 4 != 0 || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0),
+  const bool vec = (l % 4 == 0);
+  PWCLO_REQUIRE(!vec || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0),
                 "batchnorm_train_forward: x and y must be 16-byte aligned%s", "");
   const long long M = (long long)b * l;
   long long per_split;
   const int nsplit = bn_splits(c, M, &per_split);
   double *partial = reinterpret_cast<double *>(workspace);
   hipStream_t st = current_stream();
-  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x,
-                     (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, partial);
+  const float *none = nullptr;
+  hipLaunchKernelGGL((bn_partial_kernel<0, false>), dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x,
+                     none, none, none, none, none, partial);
   hipLaunchKernelGGL(bn_forward_finish_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, st, c, nsplit, M, eps, momentum,
                      partial, running_mean, running_var, save_mean, save_invstd);
-  const bool vec = (l % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  if (vec)
-    hipLaunchKernelGGL((bn_apply_kernel<0, true>), dim3(ceil_div(l, 4 * BN_THREADS), c, b), dim3(BN_THREADS), 0, st, c,
-                       l, 0.f, x, (const float *)nullptr, gamma, beta, save_mean, save_invstd,
-                       (const float *)nullptr, (const float *)nullptr, y);
+  if (relu)
+    bn_launch_apply<0, true>(vec, b, c, l, 0.f, x, none, gamma, beta, save_mean, save_invstd, none, none, y, st);
   else
-    hipLaunchKernelGGL((bn_apply_kernel<0, false>), dim3(ceil_div(l, BN_THREADS), c, b), dim3(BN_THREADS), 0, st, c,
-                       l, 0.f, x, (const float *)nullptr, gamma, beta, save_mean, save_invstd,
-                       (const float *)nullptr, (const float *)nullptr, y);
+    bn_launch_apply<0, false>(vec, b, c, l, 0.f, x, none, gamma, beta, save_mean, save_invstd, none, none, y, st);
   check_launch("batchnorm_train_forward");
 }
 
 extern "C" void batchnorm_train_backward_kernel_wrapper(int b, int c, int l, const float *x, const float *dy,
-                                                        const float *gamma, const float *save_mean,
-                                                        const float *save_invstd, float *dx, float *dgamma,
-                                                        float *dbeta, void *workspace) {
+                                                        const float *gamma, const float *beta,
+                                                        const float *save_mean, const float *save_invstd, float *dx,
+                                                        float *dgamma, float *dbeta, void *workspace, int relu) {
   if (b <= 0 || c <= 0 || l <= 0) return;
   PWCLO_REQUIRE(b <= 65535 && c <= 65535, "batchnorm_train_backward: b=%d c=%d exceed the grid limits", b, c);
+  const bool vec = (l % 4 == 0);
+  PWCLO_REQUIRE(!vec || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(dx) & 15) == 0),
+                "batchnorm_train_backward: x, dy and dx must be 16-byte aligned%s", "");
   const long long M = (long long)b * l;
   long long per_split;
   const int nsplit = bn_splits(c, M, &per_split);
   double *partial = reinterpret_cast<double *>(workspace);
   hipStream_t st = current_stream();
-  const bool vec = (l % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0);
-  PWCLO_REQUIRE(l % 4 != 0 || vec, "batchnorm_train_backward: x, dy and dx must be 16-byte aligned%s", "");
-  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x, dy,
-                     save_mean, save_invstd, partial);
+  if (relu)
+    hipLaunchKernelGGL((bn_partial_kernel<1, true>), dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x, dy,
+                       save_mean, save_invstd, gamma, beta, partial);
+  else
+    hipLaunchKernelGGL((bn_partial_kernel<1, false>), dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x,
+                       dy, save_mean, save_invstd, gamma, beta, partial);
   hipLaunchKernelGGL(bn_backward_finish_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, st, c, nsplit, partial, dgamma,
                      dbeta);
   const float inv_m = (float)(1.0 / (double)M);
-  if (vec)
-    hipLaunchKernelGGL((bn_apply_kernel<1, true>), dim3(ceil_div(l, 4 * BN_THREADS), c, b), dim3(BN_THREADS), 0, st, c,
-                       l, inv_m, x, dy, gamma, (const float *)nullptr, save_mean, save_invstd, dgamma, dbeta, dx);
+  if (relu)
+    bn_launch_apply<1, true>(vec, b, c, l, inv_m, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, dx, st);
   else
-    hipLaunchKernelGGL((bn_apply_kernel<1, false>), dim3(ceil_div(l, BN_THREADS), c, b), dim3(BN_THREADS), 0, st, c,
-                       l, inv_m, x, dy, gamma, (const float *)nullptr, save_mean, save_invstd, dgamma, dbeta, dx);
+    bn_launch_apply<1, false>(vec, b, c, l, inv_m, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, dx, st);
   check_launch("batchnorm_train_backward");
 }

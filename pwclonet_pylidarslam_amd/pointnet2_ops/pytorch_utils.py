@@ -90,6 +90,18 @@ class _ConvBlock(nn.Sequential):
                 self.add_module(name + "activation", activation)
 
 
+    def forward(self, x):
+        # training mode, post-activation order [conv, bn, ReLU]: BatchNorm and ReLU in one pass over the activations
+        mods = list(self)
+        if (_USE_HIP_BN and len(mods) == 3 and isinstance(mods[1], _BN) and type(mods[2]) is nn.ReLU
+                and isinstance(mods[0], (nn.Conv1d, nn.Conv2d, nn.Conv3d)) and mods[1][0].training):
+            y = mods[0](x)
+            if _hip_bn.supported(y, mods[1][0]):
+                return _hip_bn.batch_norm_train(y, mods[1][0], relu=True)
+            return mods[2](mods[1](y))
+        return super().forward(x)
+
+
 class Conv1d(_ConvBlock):
     def __init__(self, in_size: int, out_size: int, *, kernel_size: int = 1, stride: int = 1,
                  padding=0, activation=nn.ReLU(inplace=True), bn: bool = False,

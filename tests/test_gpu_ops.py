@@ -412,8 +412,8 @@ def test_deterministic_scatter_grad(cuda, b, c, n, s, k):
 
 
 @pytest.mark.parametrize("shape", [(4, 8, 300, 7), (8, 16, 2048, 32), (2, 64, 1, 5), (3, 5, 1000), (32, 128, 64, 8)])
-@pytest.mark.parametrize("affine", [True, False])
-def test_batchnorm_train_kernels(cuda, shape, affine):
+@pytest.mark.parametrize("affine,relu", [(True, False), (False, False), (True, True)])
+def test_batchnorm_train_kernels(cuda, shape, affine, relu):
     """training-mode BatchNorm on the HIP kernels equals a float64 evaluation of
     torch.nn.functional.batch_norm(training=True) -- output, running statistics, num_batches_tracked, and the
     gradients of input / weight / bias -- and is what the pytorch_utils BatchNorm wrappers run in train mode."""
@@ -434,11 +434,15 @@ def test_batchnorm_train_kernels(cuda, shape, affine):
                 m.weight.copy_(torch.linspace(0.7, 1.3, C))
                 m.bias.copy_(torch.linspace(-0.2, 0.2, C))
     xr = x.double().requires_grad_(True)
-    yr = ref(xr)
+    pre = ref(xr)
+    yr = torch.relu(pre) if relu else pre
+    # fused ReLU: the mask is decided in fp32; keep the comparison away from outputs within rounding of zero
+    if relu:
+        go = go * (pre.detach().abs() > 1e-4).float()
     yr.backward(go.double())
     xg = x.to(cuda).requires_grad_(True)
     assert hip_bn.supported(xg, bn)
-    yg = hip_bn.batch_norm_train(xg, bn)
+    yg = hip_bn.batch_norm_train(xg, bn, relu=relu)
     yg.backward(go.to(cuda))
 
     def close(a, b, tol):
@@ -452,7 +456,7 @@ def test_batchnorm_train_kernels(cuda, shape, affine):
     if affine:
         close(bn.weight.grad, ref.weight.grad, 2e-6)
         close(bn.bias.grad, ref.bias.grad, 2e-6)
-    if len(shape) == 4 and affine:   # the wrapper module takes this path in train mode and torch's in eval mode
+    if len(shape) == 4 and affine and not relu:   # the wrapper module takes this path in train mode and torch's in eval mode
         w = PT.BatchNorm2d(C).to(cuda)
         w.load_state_dict({"bn." + k: v for k, v in bn.state_dict().items()})
         w.train()
