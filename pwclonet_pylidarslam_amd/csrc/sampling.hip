@@ -333,20 +333,33 @@ __global__ __launch_bounds__(T) void fps_stream_kernel(int n, int m, int bs, int
 // Clouds too large for one workgroup's registers (n > 24576, e.g. raw 120k-point KITTI-360 frames
 // sampled to 8192): G workgroups of 1024 threads share one cloud, every point still lives in a VGPR
 // for the whole call, and each iteration ends in one cross-workgroup exchange through global memory:
-//   workgroup-local arg-max (as fps_reg_kernel) -> its leader posts the key with a device-scope
-//   atomic max into a rotating global slot, arrives on a per-cloud counter (release), spins until all
-//   G have arrived (acquire), reads the winning key and broadcasts it through LDS.
+//   workgroup-local arg-max (as fps_reg_kernel) -> the lane that OWNS the local winner posts
+//   (value, priority, x, y, z) into its workgroup's slot, five 64-bit words each tagged with the iteration
+//   number -> wave 0 of every workgroup polls the G slots (lane g reads workgroup g's five words) until
+//   all carry the current tag, reduces them to the global winner and broadcasts key AND coordinates
+//   through LDS.  One store burst and (typically) one or two poll round trips per iteration; no atomic
+//   read-modify-write, no arrival counter, no re-zeroing, and the next iteration needs no coordinate load.
+//   Two slot sets alternate: a workgroup can only post iteration it+2 after every workgroup has posted it+1,
+//   i.e. after every workgroup has finished polling iteration it.
 // Virtual thread id vtid = g*1024 + tid over T_total = G*1024 >= bs threads reproduces exactly the
 // E == 0 indexing of fps_reg_kernel (thread owns residue vtid mod bs, points k = vtid + T_total*i),
 // hence the same tie rule.  All G*clouds workgroups of a launch must be resident together (the host
 // launches at most 224 at a time); every spin is bounded, a timeout raises the error word and ends
-// the kernel.  Workspace (the reference's `temp` scratch): 8 u64 per cloud, zeroed by fps_coop_init.
+// the kernel.  Workspace (the reference's `temp` scratch): COOP_WS_WORDS u64 per cloud, zeroed by
+// fps_coop_init (tag 0 never matches an iteration >= 1).
 constexpr int COOP_T = 1024;
-constexpr int COOP_WS_WORDS = 8;     // u64 per cloud: [0..2] rotating key slots, [3] arrivals, [4] error
+constexpr int COOP_MAX_G = 32;
+constexpr int COOP_SLOT_WORDS = 5;                                       // value, priority, x, y, z
+constexpr int COOP_WS_WORDS = 2 * COOP_MAX_G * COOP_SLOT_WORDS + 8;       // two sets + error word (+ padding)
 
 __global__ void fps_coop_init_kernel(unsigned long long *ws, int nwords) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nwords) ws[i] = 0ull;
+}
+
+__device__ __forceinline__ void coop_post(unsigned long long *w, unsigned payload, unsigned tag) {
+  __hip_atomic_store(w, ((unsigned long long)payload << 32) | (unsigned long long)tag, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int I>
@@ -356,15 +369,16 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
                                                           int *__restrict__ idxs,
                                                           float *__restrict__ new_xyz) {
   __shared__ unsigned long long slots[3];
-  __shared__ unsigned long long bcast;
+  __shared__ unsigned long long bcast;      // winning key, ~0 = timed out
+  __shared__ float bxyz[3];                 // its coordinates
   const int g = blockIdx.x, cloud = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int vtid = g * COOP_T + tid, ttotal = G * COOP_T;
   const float *pts = dataset + (size_t)cloud * n * 3;
   int *out = idxs + (size_t)cloud * m;
   float *oxyz = new_xyz ? new_xyz + (size_t)cloud * m * 3 : nullptr;
-  unsigned long long *gslot = ws + (size_t)cloud * COOP_WS_WORDS;
-  unsigned long long *arrive = gslot + 3, *errw = gslot + 4;
+  unsigned long long *gws = ws + (size_t)cloud * COOP_WS_WORDS;
+  unsigned long long *errw = gws + 2 * COOP_MAX_G * COOP_SLOT_WORDS;
 
   float x[I], y[I], z[I];
   int td[I];
@@ -385,15 +399,12 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
     slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull;
     if (g == 0) out[0] = 0;
   }
+  float x1 = pts[0], y1 = pts[1], z1 = pts[2];     // sample 0 is point 0
+  if (oxyz && g == 0 && tid == 0) { oxyz[0] = x1; oxyz[1] = y1; oxyz[2] = z1; }
   __syncthreads();
 
-  int old = 0;
   bool failed = false;
   for (int it = 1; it < m && !failed; ++it) {
-    const float x1 = pts[(size_t)old * 3 + 0], y1 = pts[(size_t)old * 3 + 1], z1 = pts[(size_t)old * 3 + 2];
-    if (oxyz && g == 0 && tid == 0) {
-      oxyz[(it - 1) * 3 + 0] = x1; oxyz[(it - 1) * 3 + 1] = y1; oxyz[(it - 1) * 3 + 2] = z1;
-    }
     int best = __float_as_int(-1.0f), bestj = 0;
 #pragma unroll
     for (int j = 0; j < I; ++j) {
@@ -415,43 +426,81 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
     unsigned long long *slot = slots + (it % 3);
     if (lane == 0) atomicMax(slot, key);
     __syncthreads();
+    const unsigned long long lkey = *slot;
+    unsigned long long *mys = gws + ((size_t)(it & 1) * COOP_MAX_G + g) * COOP_SLOT_WORDS;
+    const unsigned tag = (unsigned)it;
+    if (lkey != 0ull && key == lkey && mine == wmax && mypri == wpri) {
+      // exactly one lane of the workgroup: it owns the local winner and has its coordinates in registers
+      float px = x[0], py = y[0], pz = z[0];
+#pragma unroll
+      for (int j = 1; j < I; ++j)
+        if (bestj == j) { px = x[j]; py = y[j]; pz = z[j]; }
+      coop_post(mys + 2, __float_as_uint(px), tag);
+      coop_post(mys + 3, __float_as_uint(py), tag);
+      coop_post(mys + 4, __float_as_uint(pz), tag);
+      coop_post(mys + 1, (unsigned)(lkey & 0xFFFFFFFFull), tag);
+      coop_post(mys + 0, (unsigned)(lkey >> 32), tag);
+    }
     if (tid == 0) {
-      const unsigned long long lkey = *slot;
       slots[(it + 2) % 3] = 0ull;
-      unsigned long long *gs = gslot + (it % 3);
-      if (lkey != 0ull) __hip_atomic_fetch_max(gs, lkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(arrive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long target = (unsigned long long)G * (unsigned long long)it;
-      unsigned long long gkey = ~0ull;   // ~0 = "timed out"
-      for (int spin = 0; spin < (1 << 22); ++spin) {
-        if (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) {
-          gkey = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
+      if (lkey == 0ull)                                  // no candidate in this workgroup: value 0
+        for (int w = 0; w < COOP_SLOT_WORDS; ++w) coop_post(mys + w, 0u, tag);
+    }
+    if (tid < 64) {                                      // wave 0 polls: lane q reads workgroup q's slot
+      const unsigned long long *qs = gws + ((size_t)(it & 1) * COOP_MAX_G + lane) * COOP_SLOT_WORDS;
+      unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull, w3 = 0ull, w4 = 0ull;
+      bool done = false;
+      for (int spin = 0; spin < (1 << 21); ++spin) {
+        bool ready = true;
+        if (lane < G) {
+          w0 = __hip_atomic_load(qs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w1 = __hip_atomic_load(qs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w2 = __hip_atomic_load(qs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w3 = __hip_atomic_load(qs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w4 = __hip_atomic_load(qs + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ready = (unsigned)w0 == tag && (unsigned)w1 == tag && (unsigned)w2 == tag && (unsigned)w3 == tag &&
+                  (unsigned)w4 == tag;
         }
-        if (__hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
-        __builtin_amdgcn_s_sleep(2);
+        if (__ballot(ready) == ~0ull) { done = true; break; }
+        if ((spin & 63) == 63 &&
+            __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+        __builtin_amdgcn_s_sleep(1);
       }
-      if (gkey == ~0ull) __hip_atomic_store(errw, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // slot (it+2)%3 was last read at iteration it-1, i.e. before every leader's arrival above
-      else if (g == 0) __hip_atomic_store(gslot + ((it + 2) % 3), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bcast = gkey;
+      const unsigned val = lane < G ? (unsigned)(w0 >> 32) : 0u;
+      const unsigned low = lane < G ? (unsigned)(w1 >> 32) : 0u;      // 0xFFFFFFFF - priority
+      const unsigned vmax = wave_reduce_u32(val, OpMaxU32());
+      const unsigned lmax = wave_reduce_u32(val == vmax ? low : 0u, OpMaxU32());
+      const unsigned long long win = __ballot(lane < G && val == vmax && low == lmax);
+      const int wl = win != 0ull ? __builtin_ctzll(win) : 0;
+      const float wx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w2 >> 32), wl));
+      const float wy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w3 >> 32), wl));
+      const float wz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w4 >> 32), wl));
+      if (lane == 0) {
+        if (!done) {
+          __hip_atomic_store(errw, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bcast = ~0ull;
+        } else {
+          bcast = vmax == 0u ? 0ull : (((unsigned long long)vmax << 32) | (unsigned long long)lmax);
+          bxyz[0] = wx; bxyz[1] = wy; bxyz[2] = wz;
+        }
+      }
     }
     __syncthreads();
     const unsigned long long kmax = bcast;
+    int old = 0;
     if (kmax == ~0ull) {
       failed = true;
-    } else if (kmax == 0ull) {
-      old = 0;
+    } else if (kmax == 0ull) {       // nothing left to sample anywhere: index 0 again, like the reference
+      x1 = pts[0]; y1 = pts[1]; z1 = pts[2];
     } else {
       const unsigned p = 0xFFFFFFFFu - (unsigned)(kmax & 0xFFFFFFFFull);
       old = (int)fps_bitrev(p >> PRI_SHIFT, log2bs) + bs * (int)(p & ((1u << PRI_SHIFT) - 1u));
+      x1 = bxyz[0]; y1 = bxyz[1]; z1 = bxyz[2];
     }
-    if (g == 0 && tid == 0 && !failed) out[it] = old;
-  }
-  if (oxyz && g == 0 && tid == 0 && !failed) {
-    oxyz[(m - 1) * 3 + 0] = pts[(size_t)old * 3 + 0];
-    oxyz[(m - 1) * 3 + 1] = pts[(size_t)old * 3 + 1];
-    oxyz[(m - 1) * 3 + 2] = pts[(size_t)old * 3 + 2];
+    if (g == 0 && tid == 0 && !failed) {
+      out[it] = old;
+      if (oxyz) { oxyz[it * 3 + 0] = x1; oxyz[it * 3 + 1] = y1; oxyz[it * 3 + 2] = z1; }
+    }
   }
 }
 
@@ -574,7 +623,8 @@ static void fps_dispatch(int b, int n, int m, const float *dataset, float *temp,
   static int coop = -1;
   if (coop < 0) { const char *e = getenv("PWCLO_FPS_COOP"); coop = e ? atoi(e) : 1; }
   const int G = ceil_div(n, COOP_T * 16);                // workgroups per cloud, <= 16 points per thread
-  if (coop && G <= 32 && (reinterpret_cast<uintptr_t>(temp) & 7) == 0 && (size_t)b * COOP_WS_WORDS * 2 <= (size_t)b * n) {
+  // (8 points per thread on twice the workgroups was measured slower: 3.2 vs 2.9 us per iteration at n = 120k)
+  if (coop && G <= COOP_MAX_G && (reinterpret_cast<uintptr_t>(temp) & 7) == 0 && (size_t)COOP_WS_WORDS * 2 <= (size_t)n) {
     // cooperative multi-workgroup sampler; `temp` doubles as its (re-zeroed) exchange workspace
     unsigned long long *ws = reinterpret_cast<unsigned long long *>(temp);
     hipStream_t st = current_stream();
