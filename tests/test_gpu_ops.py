@@ -108,7 +108,8 @@ def test_fps_large_cloud_cooperative(cuda, b, n, m, lattice):
 
 
 # ---------------------------------------------------------------- gather / group (+ grads)
-@pytest.mark.parametrize("b,c,n,m", [(2, 3, 8192, 2048), (3, 3, 256, 64), (2, 7, 100, 33), (1, 64, 1024, 1)])
+@pytest.mark.parametrize("b,c,n,m", [(2, 3, 8192, 2048), (3, 3, 256, 64), (2, 7, 100, 33), (1, 64, 1024, 1),
+                                     (2, 3, 50000, 4096), (30, 16, 512, 128)])
 def test_gather_points(cuda, b, c, n, m):
     gen = torch.Generator().manual_seed(b * c + n)
     p = torch.randn(b, c, n, generator=gen)
@@ -134,7 +135,12 @@ def test_group_points(cuda, b, c, n, s, k):
     assert torch.equal(out, O.group_points(p, idx))
 
 
-@pytest.mark.parametrize("b,c,n,s,k", [(2, 16, 2048, 1024, 32), (2, 64, 256, 64, 16), (1, 5, 77, 13, 3)])
+# shapes reach every dispatch of the LDS-accumulating kernel: 8 / 4 / 2 / 1 channels per slice (n up to 32768),
+# position ranges split over several workgroups (few clouds x slices) or not (>= 64), odd P (scalar loads), and
+# the global-atomic fallback (n > 32768)
+@pytest.mark.parametrize("b,c,n,s,k", [(2, 16, 2048, 1024, 32), (2, 64, 256, 64, 16), (1, 5, 77, 13, 3),
+                                       (16, 64, 1024, 512, 8), (2, 12, 8192, 1000, 4), (3, 9, 16000, 300, 7),
+                                       (2, 5, 30000, 700, 3), (1, 4, 40000, 600, 4), (40, 16, 100, 50, 2)])
 def test_group_points_grad(cuda, b, c, n, s, k):
     gen = torch.Generator().manual_seed(c * n + s * k + 1)
     go = torch.randn(b, c, s, k, generator=gen)
@@ -183,7 +189,8 @@ def test_three_nn(cuda, b, n, m):
     assert torch.equal(d.cpu(), d_ref)
 
 
-@pytest.mark.parametrize("b,c,m,n", [(2, 64, 64, 256), (2, 64, 256, 1024), (1, 5, 9, 31)])
+@pytest.mark.parametrize("b,c,m,n", [(2, 64, 64, 256), (2, 64, 256, 1024), (1, 5, 9, 31), (20, 64, 300, 1200),
+                                     (1, 6, 20000, 5000), (2, 3, 40000, 900)])
 def test_three_interpolate(cuda, b, c, m, n):
     gen = torch.Generator().manual_seed(c + m + n)
     p = torch.randn(b, c, m, generator=gen)
