@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--npoints", type=int, default=8192)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one multi-tensor kernel")
     ap.add_argument("--graph", action="store_true",
                     help="capture forward + loss + backward + Adam into one hipGraph (single GPU only)")
     a = ap.parse_args()
@@ -47,7 +48,7 @@ def main():
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], broadcast_buffers=False)
     opt = torch.optim.Adam(list(net.parameters()) + list(loss_mod.parameters()), lr=1e-4,
-                           capturable=a.graph)
+                           capturable=a.graph, fused=True if a.fused_adam else None)
     x1, x2 = bench.make_batch(a.batch, a.npoints, 2000 + rank, dev)
     g = torch.Generator().manual_seed(3 + rank)
     gt = torch.randn(a.batch, 7, generator=g) * 0.1
