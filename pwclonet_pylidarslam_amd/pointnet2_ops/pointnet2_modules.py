@@ -147,8 +147,7 @@ class PointnetSAModulePWCLONet(nn.Module):
                 ) -> Tuple[torch.Tensor, torch.Tensor]:
         """xyz (B,N,3), features (B,C,N) or None -> new_xyz (B,npoint,3), (B,mlp[-1],npoint)."""
         xyz_flipped = xyz.transpose(1, 2).contiguous()
-        fps_idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-        new_xyz = pointnet2_utils.gather_operation(xyz_flipped, fps_idx).transpose(1, 2).contiguous()
+        new_xyz = pointnet2_utils.sample_and_gather(xyz, self.npoint)   # == furthest_point_sample + gather_operation
         _, idx_q = pt_utils.knn_point(self.nsample, xyz, new_xyz)
         grouped_xyz = pointnet2_utils.grouping_operation(xyz_flipped, idx_q)
         xyz_diff = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)

@@ -5,6 +5,8 @@ Differentiability matches the reference: FPS / three_nn / ball_query outputs are
 non-differentiable and their backward returns ``()``; gather / group / three_interpolate send
 the gradient to ``features`` only (``grad_out.contiguous()`` first, :97,185,235).
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -26,6 +28,37 @@ class FurthestPointSampling(Function):
 
 
 furthest_point_sample = FurthestPointSampling.apply
+
+_USE_FPS_CHAIN = os.environ.get("PWCLO_FPS_CHAIN", "1") != "0"
+_CHAIN_ATTR = "_pwclo_fps_chain"
+
+
+def sample_and_gather(xyz, npoint):
+    """``furthest_point_sample`` + ``gather_operation`` of the coordinates in one sampler launch:
+    xyz (B,N,3) -> new_xyz (B,npoint,3), identical to the two separate calls.
+
+    Sampling chains (csrc/sampling.hip): a pyramid samples each level from the previous level's samples, in
+    sampling order, and such a call returns the prefix of its input unless the producing call met an exact
+    distance tie.  The first call of a chain records its tie events; the record travels as an attribute of the
+    returned tensor, and a later call on THAT tensor (same object, not modified in place since) writes its result
+    from the record instead of running the full sampler.  Falls back to the two separate calls whenever that does
+    not apply (coordinates that require grad, CPU tensors -> the ext raises as before, ``PWCLO_FPS_CHAIN=0``)."""
+    if not (_USE_FPS_CHAIN and xyz.is_cuda and xyz.dtype == torch.float32 and not xyz.requires_grad
+            and xyz.dim() == 3 and xyz.is_contiguous() and npoint >= 4):
+        idx = furthest_point_sample(xyz, npoint)
+        return gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+    from .. import fused
+    rec = getattr(xyz, _CHAIN_ATTR, None)
+    if rec is not None and rec[2] == xyz._version and npoint <= rec[1] and npoint <= xyz.shape[1]:
+        _, new_xyz = fused.fps_with_xyz(xyz, npoint, prefix_in=rec[0])
+        root = rec
+    else:
+        tie_iters = npoint // 2
+        record = torch.empty((xyz.shape[0], fused.FPS_CHAIN_INTS), dtype=torch.int32, device=xyz.device)
+        _, new_xyz = fused.fps_with_xyz(xyz, npoint, tie_out=record, tie_iters=tie_iters)
+        root = (record, tie_iters, 0)
+    setattr(new_xyz, _CHAIN_ATTR, (root[0], root[1], new_xyz._version))
+    return new_xyz
 
 
 _DETERMINISTIC = None

@@ -474,3 +474,34 @@ def test_batchnorm_train_kernels(cuda, shape, affine, relu):
         bn.eval()
         ref2 = bn(x.to(cuda))             # eval with the statistics after ONE update; w has had two
         assert not torch.equal(ref2, y3)
+
+
+def test_sample_and_gather_chain_on_module_path(cuda):
+    """pointnet2_utils.sample_and_gather (what the SA modules call): a pyramid sampled through the chain record that
+    travels on the returned tensors equals separate furthest_point_sample + gather_operation calls at every level --
+    on lidar-shaped clouds, on an integer lattice (exact ties -> fallback flag) and after an in-place edit of a level's
+    coordinates (record dropped: version counter)."""
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pointnet2_utils as PU
+    pc1, _, _, _ = synthetic.kitti_like_pair(321, 8192, 3)
+    lattice = torch.stack(torch.meshgrid(torch.arange(16.), torch.arange(16.), torch.arange(8.), indexing="ij"),
+                          dim=-1).reshape(1, 2048, 3).repeat(2, 1, 1) + 1.0
+
+    def plain(x, m):
+        idx = PU.furthest_point_sample(x, m)
+        return PU.gather_operation(x.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+
+    for cloud, levels in ((torch.from_numpy(pc1[:, :, :3].copy()).float(), (2048, 1024, 256, 64)),
+                          (lattice, (1024, 512, 256, 64))):
+        x = cloud.to(cuda).contiguous()
+        chained, ref = x, x.clone()
+        for lvl, m in enumerate(levels):
+            chained = PU.sample_and_gather(chained, m)
+            ref = plain(ref.clone(), m)                       # clone: no record attached
+            assert torch.equal(chained, ref), (lvl, m)
+            assert hasattr(chained, PU._CHAIN_ATTR)
+        # the last level of frame-1's pyramid is sampled twice in PWCLO-Net (flow_feature_encoding): same record
+        assert torch.equal(PU.sample_and_gather(chained, 16), plain(ref.clone(), 16))
+    # in-place edit invalidates the record: the next level must be sampled from the edited coordinates
+    lvl1 = PU.sample_and_gather(torch.from_numpy(pc1[:1, :, :3].copy()).float().to(cuda).contiguous(), 2048)
+    lvl1[:, :100] += 5.0
+    assert torch.equal(PU.sample_and_gather(lvl1, 1024), plain(lvl1.clone(), 1024))
