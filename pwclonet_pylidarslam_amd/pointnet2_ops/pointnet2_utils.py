@@ -209,15 +209,14 @@ class QueryAndGroupVoteNet(nn.Module):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         if self.sample_uniformly:
             # host loop over balls like the reference (a VoteNet training option, not on PWCLO-Net's path)
-            unique_cnt = torch.zeros((idx.shape[0], idx.shape[1]))
-            for i_batch in range(idx.shape[0]):
-                for i_region in range(idx.shape[1]):
-                    unique_ind = torch.unique(idx[i_batch, i_region, :])
-                    num_unique = unique_ind.shape[0]
-                    unique_cnt[i_batch, i_region] = num_unique
-                    sample_ind = torch.randint(0, num_unique, (self.nsample - num_unique,), dtype=torch.long,
-                                               device=idx.device)
-                    idx[i_batch, i_region, :] = torch.cat((unique_ind, unique_ind[sample_ind]))
+            B, M = idx.shape[0], idx.shape[1]
+            unique_cnt = torch.zeros((B, M))
+            for ball in range(B * M):
+                b, r = divmod(ball, M)
+                members = torch.unique(idx[b, r])
+                unique_cnt[b, r] = members.numel()
+                refill = torch.randint(0, members.numel(), (self.nsample - members.numel(),), device=idx.device)
+                idx[b, r] = torch.cat((members, members[refill]))
         grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
         grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
         if self.normalize_xyz:
