@@ -129,6 +129,17 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_mfma_busy(kernel):
+    """Share of SIMD time the matrix pipe was executing during `kernel`, from the committed SQ counter pass
+    (profiles/pmc_mfma_busy.json, tools/pmc_mfma.py): includes the MFMA work spent on padded channels / pixels,
+    which `achieved` (algorithmic FLOP) does not count.  None if not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_mfma_busy.json")) as f:
+            return json.load(f).get(kernel, {}).get("mfma_busy")
+    except (OSError, ValueError):
+        return None
+
+
 def roofline_objects(fam):
     total_ms = sum(d["ms"] for d in fam.values()) or 1.0
     mlp = fam.get("mlp", {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "by_name": {}})
@@ -140,7 +151,7 @@ def roofline_objects(fam):
     fam_tf = mlp["flops"] / 1e12 / (mlp["ms"] / 1e3) if mlp["ms"] > 0 else 0.0
     traffic = pmc_traffic(name)
     roof = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "mfma_busy_pmc": pmc_mfma_busy(name),
             "launches_per_step": dom["launches"], "avg_launch_us": 1e3 * dom["ms"] / n,
             "algorithmic_gflop_per_launch": dom["flops"] / 1e9 / n,
             "algorithmic_mb_per_launch": dom["bytes"] / 1e6 / n,

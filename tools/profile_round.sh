@@ -20,6 +20,8 @@ cp "$(find $out/default -name '*kernel_stats.csv' | head -1)" $out/${tag}_defaul
 cp "$(find $out/eager -name '*kernel_stats.csv' | head -1)" $out/${tag}_eager_inflight1_kernel_stats.csv
 python tools/pmc_traffic.py "$(find $out/fetch -name '*counter_collection.csv' | head -1)" \
        "$(find $out/write -name '*counter_collection.csv' | head -1)" -o $out/pmc_traffic.json
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out/sq -o sq -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
+python tools/pmc_mfma.py "$(find $out/sq -name '*counter_collection.csv' | head -1)" -o $out/pmc_mfma_busy.json > $out/pmc_mfma_busy.txt
 tail -c 400 $out/${tag}_default_bench_under_rocprof.json; echo
 tail -c 400 $out/${tag}_eager_inflight1_under_rocprof.json; echo
 ls -la $out
