@@ -52,7 +52,7 @@ __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<
   const int pix_per_cloud = (S_) * (KP_);                                                           \
   const int tiles_per_cloud = (pix_per_cloud + TILE - 1) / TILE;                                    \
   const int ntiles = (B_) * tiles_per_cloud;                                                        \
-  for (int t = blockIdx.x * W + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * W)
+  for (int t = blockIdx.x * W + wave_index(); t < ntiles; t += gridDim.x * W)
 
 // ---- per-point linear maps (the hoisted partial products) -----------------------------------------
 struct LinJob {
@@ -69,16 +69,16 @@ __device__ __forceinline__ void linear_tiles(const LinJob &jb, const float *lds_
   constexpr int P = 2;
   const int g = lane >> 4, j = lane & 15;
   const int ntiles = (jb.npts + 16 * P - 1) / (16 * P);
-  for (int t = blockIdx.x * LIN_WAVES + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * LIN_WAVES) {
+  for (int t = blockIdx.x * LIN_WAVES + wave_index(); t < ntiles; t += gridDim.x * LIN_WAVES) {
     f32x4 in[NBI][P];
     int pt[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int q = t * 16 * P + 16 * p + j;
       pt[p] = q < jb.npts ? q : -1;
-      const float *row = jb.src + (size_t)(q < jb.npts ? q : jb.npts - 1) * (16 * NBI);
+      const float *row = at32(jb.src, (unsigned)(q < jb.npts ? q : jb.npts - 1) * (unsigned)(64 * NBI) + 16u * (unsigned)g);
 #pragma unroll
-      for (int m = 0; m < NBI; ++m) in[m][p] = ld4(row + 16 * m + 4 * g);
+      for (int m = 0; m < NBI; ++m) in[m][p] = ld4(row + 16 * m);
     }
     f32x4 o1[NBO][P];
     mlp_layer<NBI, NBO, P, false>(o1, in, lds_w, lane);
@@ -87,7 +87,8 @@ __device__ __forceinline__ void linear_tiles(const LinJob &jb, const float *lds_
 #pragma unroll
       for (int p = 0; p < P; ++p)
         if (pt[p] >= 0)
-          *reinterpret_cast<f32x4 *>(jb.out + (size_t)pt[p] * (16 * NBO) + 16 * o + 4 * g) = o1[o][p];
+          *reinterpret_cast<f32x4 *>(at32(jb.out, (unsigned)pt[p] * (unsigned)(64 * NBO) + 64u * o + 16u * (unsigned)g)) =
+              o1[o][p];
   }
 }
 
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
   PWCLO_H_TILE_LOOP(KP, P, a.S, a.B) {
     const int b = t / tiles_per_cloud;
     const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    const unsigned bS = (unsigned)b * (unsigned)a.S, bN = (unsigned)b * (unsigned)a.N;   // scalar
     f32x4 in[1][P];
     int sq[P];
     const float *prow[P];
@@ -133,12 +135,14 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
       const int s = valid ? pm.s : a.S - 1;
       const int k = pm.k < a.K ? pm.k : 0;
       sq[p] = valid ? s : -1;
-      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
-      const float *c = a.new_xyz + ((size_t)b * a.S + s) * 3;
-      const float *q = a.xyz + ((size_t)b * a.N + nbr) * 3;
+      const unsigned row = bS + (unsigned)s;
+      const int nbr = *at32(a.idx, (mul24(row, (unsigned)a.K) + (unsigned)k) * 4u);
+      const float *c = at32(a.new_xyz, mul24(row, 12u));
+      const unsigned src = bN + (unsigned)nbr;
+      const float *q = at32(a.xyz, mul24(src, 12u));
       const float qx = q[0], qy = q[1], qz = q[2];
       in[0][p] = diff_block_h(qx - c[0], qy - c[1], qz - c[2], qx, qy, qz, XYZ_ONLY, g);
-      prow[p] = XYZ_ONLY ? nullptr : a.pre + ((size_t)b * a.N + nbr) * C1 + 4 * g;
+      prow[p] = XYZ_ONLY ? nullptr : at32(a.pre, src * (unsigned)(C1 * 4) + 16u * (unsigned)g);
     }
     f32x4 h1[B1][P], h2[B2][P], h3[B3][P];
     if (XYZ_ONLY) {
@@ -168,7 +172,8 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
         v.x = relu_bits(group_max_nonneg<GROUP>(v.x)); v.y = relu_bits(group_max_nonneg<GROUP>(v.y));
         v.z = relu_bits(group_max_nonneg<GROUP>(v.z)); v.w = relu_bits(group_max_nonneg<GROUP>(v.w));
         if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
-          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * C3 + 16 * o + 4 * g) = v;
+          *reinterpret_cast<f32x4 *>(at32(a.out, (bS + (unsigned)sq[p]) * (unsigned)(C3 * 4) + 64u * o +
+                                                      16u * (unsigned)g)) = v;
       }
     }
   }
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
   PWCLO_H_TILE_LOOP(KP, P, a.S, a.B) {
     const int b = t / tiles_per_cloud;
     const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    const unsigned bS = (unsigned)b * (unsigned)a.S, bN = (unsigned)b * (unsigned)a.N;   // scalar
     f32x4 in[1][P];
     int sq[P];
     const float *prow[P];
@@ -205,11 +211,13 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
       const int s = valid ? pm.s : a.S - 1;
       const int k = pm.k < a.K ? pm.k : 0;
       sq[p] = valid ? s : -1;
-      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
-      const float *c = a.xyz2 + ((size_t)b * a.S + s) * 3;
-      const float *q = a.xyz1 + ((size_t)b * a.N + nbr) * 3;
+      const unsigned row = bS + (unsigned)s;
+      const int nbr = *at32(a.idx, (mul24(row, (unsigned)a.K) + (unsigned)k) * 4u);
+      const float *c = at32(a.xyz2, mul24(row, 12u));
+      const unsigned src = bN + (unsigned)nbr;
+      const float *q = at32(a.xyz1, mul24(src, 12u));
       in[0][p] = diff_block_h(q[0] - c[0], q[1] - c[1], q[2] - c[2], 0.f, 0.f, 0.f, false, g);
-      prow[p] = a.pre + ((size_t)b * a.N + nbr) * 128 + 4 * g;
+      prow[p] = at32(a.pre, (src << 9) + 16u * (unsigned)g);          // 128 floats per row
     }
     f32x4 h1[B1][P], h2[B2][P];
 #pragma unroll
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
         v.x = relu_bits(group_max_nonneg<GROUP>(v.x)); v.y = relu_bits(group_max_nonneg<GROUP>(v.y));
         v.z = relu_bits(group_max_nonneg<GROUP>(v.z)); v.w = relu_bits(group_max_nonneg<GROUP>(v.w));
         if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
-          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = v;
+          *reinterpret_cast<f32x4 *>(at32(a.out, ((bS + (unsigned)sq[p]) << 8) + 64u * o + 16u * (unsigned)g)) = v;
       }
   }
 }
@@ -256,6 +264,8 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
   PWCLO_H_TILE_LOOP(KP, P, a.S, a.B) {
     const int b = t / tiles_per_cloud;
     const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    const unsigned bS = (unsigned)b * (unsigned)a.S, bN = (unsigned)b * (unsigned)a.N;   // scalar
+    const unsigned bPix = (unsigned)b * (unsigned)pix_per_cloud;
     f32x4 in[1][P];
     int pixv[P];
     const float *urow[P], *vrow[P];
@@ -267,10 +277,12 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
       const int s = valid ? pm.s : a.S - 1;
       const int k = pm.k < a.K ? pm.k : 0;
       pixv[p] = (valid && pm.k < a.K) ? pix : -1;      // padded slots are never read back (cv_a2)
-      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
-      in[0][p] = geometry_block_h(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
-      urow[p] = a.u + ((size_t)b * a.S + s) * 128 + 4 * g;
-      vrow[p] = a.v + ((size_t)b * a.N + nbr) * 128 + 4 * g;
+      const unsigned row = bS + (unsigned)s;
+      const int nbr = *at32(a.idx, (mul24(row, (unsigned)a.K) + (unsigned)k) * 4u);
+      const unsigned src = bN + (unsigned)nbr;
+      in[0][p] = geometry_block_h(at32(a.xyz1, mul24(row, 12u)), at32(a.xyz2, mul24(src, 12u)), g);
+      urow[p] = at32(a.u, (row << 9) + 16u * (unsigned)g);
+      vrow[p] = at32(a.v, (src << 9) + 16u * (unsigned)g);
     }
     f32x4 h1[B1][P], h2[B2][P], h3[B3][P];
 #pragma unroll
@@ -285,7 +297,8 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p)
         if (pixv[p] >= 0)
-          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * pix_per_cloud + pixv[p]) * 64 + 16 * o + 4 * g) = h3[o][p];
+          *reinterpret_cast<f32x4 *>(at32(a.out, ((bPix + (unsigned)pixv[p]) << 8) + 64u * o + 16u * (unsigned)g)) =
+              h3[o][p];
   }
 }
 
@@ -299,6 +312,7 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
   PWCLO_H_TILE_LOOP(KP, P, a.S, a.B) {
     const int b = t / tiles_per_cloud;
     const int pix0 = (t - b * tiles_per_cloud) * TILE;
+    const unsigned bS = (unsigned)b * (unsigned)a.S, bN = (unsigned)b * (unsigned)a.N;   // scalar
     f32x4 geo[1][P], val[4][P];
     int sq[P];
     bool padded[P];
@@ -311,11 +325,13 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
       padded[p] = pm.k >= a.K;
       const int k = padded[p] ? 0 : pm.k;
       sq[p] = valid ? s : -1;
-      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
-      geo[0][p] = geometry_block_h(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
-      urow[p] = a.u + ((size_t)b * a.S + s) * 128 + 4 * g;
-      vrow[p] = a.v + ((size_t)b * a.N + nbr) * 128 + 4 * g;
-      const float *fr = a.val + ((size_t)b * a.N + nbr) * 64 + 4 * g;
+      const unsigned row = bS + (unsigned)s;
+      const int nbr = *at32(a.idx, (mul24(row, (unsigned)a.K) + (unsigned)k) * 4u);
+      const unsigned src = bN + (unsigned)nbr;
+      geo[0][p] = geometry_block_h(at32(a.xyz1, mul24(row, 12u)), at32(a.xyz2, mul24(src, 12u)), g);
+      urow[p] = at32(a.u, (row << 9) + 16u * (unsigned)g);
+      vrow[p] = at32(a.v, (src << 9) + 16u * (unsigned)g);
+      const float *fr = at32(a.val, (src << 8) + 16u * (unsigned)g);
 #pragma unroll
       for (int m = 0; m < 4; ++m) val[m][p] = ld4(fr + 16 * m);
     }
@@ -348,7 +364,7 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
           res[c] = div_ge1(num, den);
         }
         if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
-          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = res;
+          *reinterpret_cast<f32x4 *>(at32(a.out, ((bS + (unsigned)sq[p]) << 8) + 64u * o + 16u * (unsigned)g)) = res;
       }
   }
 }
@@ -387,6 +403,7 @@ extern "C" void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int
     const bool ok = (cin[i] == 16 || cin[i] == 32 || cin[i] == 64) &&
                     (cout[i] == 16 || cout[i] == 32 || cout[i] == 64 || cout[i] == 128);
     PWCLO_REQUIRE(ok, "linear_jobs: job %d has unsupported channels %d -> %d", i, cin[i], cout[i]);
+    PWCLO_REQUIRE(rows_fit_32bit(npts[i]), "linear_jobs: job %d has too many rows for 32-bit offsets (%d)", i, npts[i]);
     a.job[i] = LinJob{src[i], w[i], out[i], npts[i], cin[i] / 16, cout[i] / 16};
     max_tiles = max(max_tiles, ceil_div(npts[i], 32));
     max_lds = max(max_lds, 4 * layer_floats(cin[i] / 16, cout[i] / 16));
@@ -403,6 +420,7 @@ extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, in
                                           const float *packed_w, float *out) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "sa_fused_h: nsample=%d outside [1,32]", k);
+  PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 32)), "sa_fused_h: batch too large for 32-bit offsets (b=%d)", b);
   SAHArgs a{xyz, new_xyz, pre, idx, packed_w, out, b, n, s, k};
   const int kp = k > 16 ? 32 : 16;
   const bool lvl0 = pre == nullptr;
@@ -436,6 +454,7 @@ extern "C" void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const 
                                               float *out) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 8, "upconv_fused_h: nsample=%d outside [1,8]", k);
+  PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 8)), "upconv_fused_h: batch too large for 32-bit offsets (b=%d)", b);
   UpHArgs a{xyz2, xyz1, pre, idx, packed_w, out, b, n, s, k};
   static bool attr = false, attr3 = false;
   constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4));
@@ -450,6 +469,7 @@ extern "C" void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const f
                                              const float *packed_w, float *pix) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a1_h: nsample_q=%d outside [1,32]", k);
+  PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 32)), "cv_fused_a1_h: batch too large for 32-bit offsets (b=%d)", b);
   CVHArgs a{xyz1, u, xyz2, v, nullptr, idx, packed_w, pix, b, n, s, k};
   const int kp = cv_pix_slots(k);
   constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4) + layer_floats(4, 4));
@@ -475,6 +495,7 @@ extern "C" void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xy
                                             const float *packed_w, float *out) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 4, "cv_fused_b_h: nsample=%d outside [1,4]", k);
+  PWCLO_REQUIRE(rows_fit_32bit((long long)b * s * 4), "cv_fused_b_h: batch too large for 32-bit offsets (b=%d)", b);
   CVHArgs a{xyz1, u2, xyz1, v2, first, idx, packed_w, out, b, s, s, k};
   static bool attr = false;
   constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(4, 8) + layer_floats(8, 4));

@@ -83,7 +83,7 @@ __device__ __forceinline__ void softmax_weighted_sum(f32x4 (&res)[P], const f32x
   const int pix_per_cloud = (S_) * (KP_);                                                           \
   const int tiles_per_cloud = (pix_per_cloud + TILE - 1) / TILE;                                    \
   const int ntiles = (B_) * tiles_per_cloud;                                                        \
-  for (int t = blockIdx.x * W + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * W)
+  for (int t = blockIdx.x * W + wave_index(); t < ntiles; t += gridDim.x * W)
 
 // ---- set-upconv: PointnetFPModulePWCLONet, knn branch up to the max (pointnet2_modules.py:479-506) --
 struct UpconvArgs {
@@ -178,10 +178,10 @@ __global__ __launch_bounds__(W * 64) void pointwise_kernel(PointwiseArgs a) {
       const bool valid = s0 < a.S;
       const int s = valid ? s0 : a.S - 1;
       sq[p] = valid ? s : -1;
-      const size_t row = (size_t)b * a.S + s;
-      load_row_blocks<NB0>(&in[0][p], P, a.src[0] + row * (16 * NB0), g);
-      if (NB1 > 0) load_row_blocks<NB1>(&in[NB0][p], P, a.src[1] + row * (16 * NB1), g);
-      if (NB2 > 0) load_row_blocks<NB2>(&in[NB0 + NB1][p], P, a.src[2] + row * (16 * NB2), g);
+      const unsigned row = (unsigned)b * (unsigned)a.S + (unsigned)s;
+      load_row_blocks<NB0>(&in[0][p], P, at32(a.src[0], row * (unsigned)(64 * NB0)), g);
+      if (NB1 > 0) load_row_blocks<NB1>(&in[NB0][p], P, at32(a.src[1], row * (unsigned)(64 * NB1)), g);
+      if (NB2 > 0) load_row_blocks<NB2>(&in[NB0 + NB1][p], P, at32(a.src[2], row * (unsigned)(64 * NB2)), g);
     }
     f32x4 h1[B1][P];
     mlp_layer<NBI, B1, P, true>(h1, in, lds_w, lane);
@@ -193,14 +193,16 @@ __global__ __launch_bounds__(W * 64) void pointwise_kernel(PointwiseArgs a) {
 #pragma unroll
         for (int p = 0; p < P; ++p)
           if (sq[p] >= 0)
-            *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * (16 * BOUT) + 16 * o + 4 * g) = h2[o][p];
+            *reinterpret_cast<f32x4 *>(at32(a.out, ((unsigned)b * (unsigned)a.S + (unsigned)sq[p]) * (unsigned)(64 * BOUT) +
+                                                        64u * o + 16u * (unsigned)g)) = h2[o][p];
     } else {
 #pragma unroll
       for (int o = 0; o < B1; ++o)
 #pragma unroll
         for (int p = 0; p < P; ++p)
           if (sq[p] >= 0)
-            *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * (16 * BOUT) + 16 * o + 4 * g) = h1[o][p];
+            *reinterpret_cast<f32x4 *>(at32(a.out, ((unsigned)b * (unsigned)a.S + (unsigned)sq[p]) * (unsigned)(64 * BOUT) +
+                                                        64u * o + 16u * (unsigned)g)) = h1[o][p];
     }
   }
 }
@@ -284,11 +286,13 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
       padded[p] = pm.k >= a.K;
       const int k = padded[p] ? 0 : pm.k;
       sq[p] = valid ? s : -1;
-      const int nbr = a.idx[((size_t)b * a.S + s) * a.K + k];
-      geo[0][p] = geometry_block(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
+      const unsigned row = (unsigned)b * (unsigned)a.S + (unsigned)s;
+      const int nbr = *at32(a.idx, (mul24(row, (unsigned)a.K) + (unsigned)k) * 4u);
+      const unsigned src = (unsigned)b * (unsigned)a.N + (unsigned)nbr;
+      geo[0][p] = geometry_block(at32(a.xyz1, mul24(row, 12u)), at32(a.xyz2, mul24(src, 12u)), g);
       // padded slots (masked below) re-read slot 0's row: a1 does not write them, no extra traffic
       const int pixc = valid ? pix - (padded[p] ? pm.k : 0) : pix_per_cloud - KP;
-      load_row_blocks<4>(&cat[4][p], P, a.pix + ((size_t)b * pix_per_cloud + pixc) * 64, g);
+      load_row_blocks<4>(&cat[4][p], P, at32(a.pix, ((unsigned)b * (unsigned)pix_per_cloud + (unsigned)pixc) << 8), g);
     }
     f32x4 enc[4][P];
     mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
@@ -308,7 +312,8 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
 #pragma unroll
       for (int p = 0; p < P; p += BPQ)
         if ((j & (GROUP - 1)) == 0 && sq[p] >= 0)
-          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = res[p];
+          *reinterpret_cast<f32x4 *>(at32(a.out, (((unsigned)b * (unsigned)a.S + (unsigned)sq[p]) << 8) + 64u * o +
+                                                      16u * (unsigned)g)) = res[p];
     }
   }
 }
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
   const bool split = i >= 6;
   const int tiles_per_cloud = (a.S + 7) / 8;
   const int ntiles = a.B * tiles_per_cloud;
-  for (int t = blockIdx.x * W + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * W) {
+  for (int t = blockIdx.x * W + wave_index(); t < ntiles; t += gridDim.x * W) {
     const int b = t / tiles_per_cloud;
     const int s0 = (t - b * tiles_per_cloud) * 8;
     f32x4 geo[1][P], cat[8][P];
@@ -345,9 +350,12 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
       const bool valid = q < a.S;
       const int s = valid ? q : a.S - 1;
       sq[p] = valid ? s : -1;
-      const int nbr = a.idx[((size_t)b * a.S + s) * 6 + k];
-      geo[0][p] = geometry_block(a.xyz1 + ((size_t)b * a.S + s) * 3, a.xyz2 + ((size_t)b * a.N + nbr) * 3, g);
-      load_row_blocks<4>(&cat[4][p], P, a.pix + (((size_t)b * a.S + s) * 6 + k) * 64, g);
+      const unsigned row = (unsigned)b * (unsigned)a.S + (unsigned)s;
+      const unsigned slot = mul24(row, 6u) + (unsigned)k;
+      const int nbr = *at32(a.idx, slot * 4u);
+      const unsigned src = (unsigned)b * (unsigned)a.N + (unsigned)nbr;
+      geo[0][p] = geometry_block(at32(a.xyz1, mul24(row, 12u)), at32(a.xyz2, mul24(src, 12u)), g);
+      load_row_blocks<4>(&cat[4][p], P, at32(a.pix, slot << 8), g);
     }
     f32x4 h2[4][P];
     if constexpr (BF3) {
@@ -403,7 +411,8 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p)
         if ((i == 0 || (i == 6 && p == 0)) && sq[p] >= 0)
-          *reinterpret_cast<f32x4 *>(a.out + ((size_t)b * a.S + sq[p]) * 64 + 16 * o + 4 * g) = res[p];
+          *reinterpret_cast<f32x4 *>(at32(a.out, (((unsigned)b * (unsigned)a.S + (unsigned)sq[p]) << 8) + 64u * o +
+                                                      16u * (unsigned)g)) = res[p];
     }
   }
 }
@@ -662,6 +671,7 @@ extern "C" void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int
                                                const float *src0, const float *src1, const float *src2,
                                                const float *packed_w, float *out) {
   if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(rows_fit_32bit((long long)b * s), "pointwise_fused: batch too large for 32-bit offsets (b=%d)", b);
   PointwiseArgs a{{src0, src1, src2}, packed_w, out, b, s, fl_tuning("PWCLO_FL_STAGGER", 0)};
 #define PW_CASE(C0, C1, C2, A1, A2)                                                                 \
   if (c0 == C0 && c1 == C1 && c2 == C2 && w1 == A1 && w2 == A2) {                                   \
@@ -721,6 +731,7 @@ extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const flo
                                            const float *pix, float *out) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a2: nsample_q=%d outside [1,32]", k);
+  PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 32)), "cv_fused_a2: batch too large for 32-bit offsets (b=%d)", b);
   CVArgs a{xyz1, nullptr, xyz2, nullptr, idx, packed_w, const_cast<float *>(pix), out, b, n, s, k,
            fl_tuning("PWCLO_FL_STAGGER", 0)};
   const int kp = cv_pix_slots(k);

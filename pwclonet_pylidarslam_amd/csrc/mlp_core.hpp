@@ -19,6 +19,7 @@
 // fp32 MFMA is bit-for-bit an fmaf chain in k order, so results differ from a CPU GEMM only by
 // summation order (parity bound 1e-5, tests/test_gpu_fused.py).
 #pragma once
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -313,6 +314,24 @@ static inline int cv_pix_slots(int k) {
   if (k == 6 && dense6) return 6;
   return k > 16 ? 32 : (k > 8 ? 16 : 8);
 }
+
+// Index of the wave inside its workgroup as a SCALAR: the compiler cannot know that threadIdx.x >> 6 is
+// wave-uniform, and without this the tile index, the cloud index (an integer division) and every per-cloud
+// base address of the tile loops are computed on the vector ALU -- which the matrix pipe waits for.
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// base + 32-bit BYTE offset: lets the compiler address global memory as (scalar base, 32-bit vector offset,
+// immediate) instead of building 64-bit addresses per lane with quarter-rate multiplies and 64-bit adds on the
+// vector ALU.  The launchers check that every such offset stays below 4 GiB.
+template <typename T>
+__device__ __forceinline__ T *at32(T *base, unsigned byte_off) {
+  using C = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+  return reinterpret_cast<T *>(reinterpret_cast<C *>(base) + (size_t)byte_off);
+}
+__device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) { return __umul24(a, b); }   // both < 2^24: full rate
+// Host-side guard of the above: `rows` rows (points or pixels over the whole batch) of at most 512 bytes each
+// must be addressable with 32 bits (and rows < 2^24 for mul24): 8.3 M rows, e.g. batch 1024 of 8192-point clouds.
+static inline bool rows_fit_32bit(long long rows) { return rows >= 0 && rows < (1ll << 23); }
 
 // pixel index -> (query s, neighbour slot k).
 template <int KP>

@@ -255,7 +255,7 @@ def test_fused_forward_is_bitwise_deterministic_and_graph_safe(cuda):
 def test_prediction_module_adapter_matches_forward(cuda):
     """frames (B, n_total, 3) through the adapter == the reference-shaped call on
     `frame[:, :num_points, :3]` permuted to (B,3,N): bitwise on the fused path (same kernels, the ingest
-    kernel only moves data), and the module route (no packed weights) is the same call."""
+    kernel only moves data); the module route (no packed weights) is the same call (equal within rounding, see below)."""
     from pwclonet_pylidarslam_amd.prediction import PWCLONetPredictionModule
     pc1, pc2, _, _ = synthetic.kitti_like_pair(43, 2304, 2)
     f1 = torch.from_numpy(pc1[:, :, :3]).contiguous().to(cuda)        # (B, 2304, 3)
@@ -269,7 +269,10 @@ def test_prediction_module_adapter_matches_forward(cuda):
     with torch.no_grad():
         ref_module, _ = mod.pwclonet(x1, None, x2, None)
         got_module, _ = mod([f1, f2])
-    assert torch.equal(got_module, ref_module)
+    # same call twice; torch's own 1x1-convolution backends are not run-to-run deterministic for every shape on this
+    # stack (observed: 4e-7 between two identical module-path forwards, first differing in a Conv1d of the pose head),
+    # so the module route is compared within rounding and only the fused route -- all kernels ours -- bitwise
+    torch.testing.assert_close(got_module, ref_module, rtol=0, atol=5e-6)
     mod.pwclonet.prepare_fused()
     with torch.no_grad():
         ref_fused, ref_log = mod.pwclonet(x1, None, x2, None)
