@@ -16,7 +16,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
     const float *__restrict__ xyz, int *__restrict__ idx) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * BQ_WAVES + (threadIdx.x >> 6);
+  const int j = blockIdx.x * BQ_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (j >= m) return;  // wave-uniform
   const float *q = new_xyz + ((size_t)b * m + j) * 3;
   const float nx = q[0], ny = q[1], nz = q[2];

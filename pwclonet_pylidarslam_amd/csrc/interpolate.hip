@@ -21,7 +21,7 @@ __global__ __launch_bounds__(NN_WAVES * 64) void three_nn_kernel(int n, int m,
                                                                  int *__restrict__ idx) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * NN_WAVES + (threadIdx.x >> 6);
+  const int j = blockIdx.x * NN_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (j >= n) return;  // wave-uniform
   const float *u = unknown + ((size_t)b * n + j) * 3;
   const float ux = u[0], uy = u[1], uz = u[2];

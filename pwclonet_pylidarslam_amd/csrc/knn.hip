@@ -120,7 +120,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(int n, int s, int K
   __shared__ u64 pools[KNN_WAVES][QPW][KNN_POOL];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: query index and addresses on the SALU
   const int q0 = (blockIdx.x * KNN_WAVES + wave) * QPW;
   if (q0 >= s) return;  // wave-uniform; the kernel uses no workgroup barrier
 
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_pruned_kernel(int nblk, in
   __shared__ u64 pools[KNN_WAVES][KNN_POOL];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: query index and addresses on the SALU
   const int q = blockIdx.x * KNN_WAVES + wave;
   if (q >= s) return;  // wave-uniform; no workgroup barrier below
   const float INF = __int_as_float(0x7f800000);
