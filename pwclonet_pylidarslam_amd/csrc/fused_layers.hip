@@ -417,6 +417,84 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
   }
 }
 
+// a2 for K == 6 with the softmax IN-LANE: a wave tile = 16 consecutive queries; pixel block p of pass `grp` holds
+// neighbour 3*grp + p of those 16 queries (lane j <-> query j), so the six logits of a query and channel sit in the
+// same lane of six blocks and the softmax-weighted sum needs no DPP step, no select and no padded lane.  The six
+// blocks run as three passes of two (256 VGPRs without spills); the passes are merged with the
+// running-maximum form of the softmax: (m, d, n) -> m' = max(m_a, m_b), d' = d_a e^(m_a-m') + d_b e^(m_b-m'), same
+// for n; out = n / d.  Same values as the direct form up to two extra roundings (1e-7 relative).
+template <int W>
+__global__ __launch_bounds__(W * 64) void cv_a2_lane6_kernel(CVArgs a) {
+  constexpr int P = 2, PASSES = 3;          // three passes of two neighbour blocks: fits 256 VGPRs without spills
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats(8, 8), W2 = layer_floats(8, 4);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, WX + W1 + W2);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int tiles_per_cloud = (a.S + 15) / 16;
+  const int ntiles = a.B * tiles_per_cloud;
+  for (int t = blockIdx.x * W + wave_index(); t < ntiles; t += gridDim.x * W) {
+    const int b = t / tiles_per_cloud;
+    const int q = (t - b * tiles_per_cloud) * 16 + j;
+    const bool valid = q < a.S;
+    const unsigned row = (unsigned)b * (unsigned)a.S + (unsigned)(valid ? q : a.S - 1);
+    const float *centre = at32(a.xyz1, mul24(row, 12u));
+    f32x4 mrun[4], drun[4], nrun[4];
+    // a real loop over the passes (not unrolled): the scheduler must not pull a later pass's gathers forward
+    auto run_pass = [&](auto first_tag, int pass) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      f32x4 geo[1][P], cat[8][P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const unsigned slot = mul24(row, 6u) + (unsigned)(P * pass + p);
+        const int nbr = *at32(a.idx, slot * 4u);
+        const unsigned src = (unsigned)b * (unsigned)a.N + (unsigned)nbr;
+        geo[0][p] = geometry_block(centre, at32(a.xyz2, mul24(src, 12u)), g);
+        load_row_blocks<4>(&cat[4][p], P, at32(a.pix, slot << 8), g);
+      }
+      f32x4 enc[4][P], h1[8][P], h2[4][P];
+      mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int p = 0; p < P; ++p) cat[m][p] = enc[m][p];
+      mlp_layer<8, 8, P, true>(h1, cat, lds_w + WX, lane);
+      mlp_layer<8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x0 = h2[o][0][c], x1 = h2[o][1][c];                     // post-ReLU: >= 0
+          const float m = max_bits(x0, x1);
+          const float e0 = exp_nonpos(x0 - m), e1 = exp_nonpos(x1 - m);
+          const float d = e0 + e1;
+          const float n = e0 * cat[4 + o][0][c] + e1 * cat[4 + o][1][c];
+          if (FIRST) {
+            mrun[o][c] = m; drun[o][c] = d; nrun[o][c] = n;
+          } else {
+            const float mm = max_bits(mrun[o][c], m);
+            const float fa = exp_nonpos(mrun[o][c] - mm), fb = exp_nonpos(m - mm);
+            mrun[o][c] = mm;
+            drun[o][c] = drun[o][c] * fa + d * fb;
+            nrun[o][c] = nrun[o][c] * fa + n * fb;
+          }
+        }
+    };
+    run_pass(std::true_type{}, 0);
+#pragma unroll 1
+    for (int pass = 1; pass < PASSES; ++pass) run_pass(std::false_type{}, pass);
+    if (valid) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        f32x4 res;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) res[c] = div_ge1(nrun[o][c], drun[o][c]);
+        *reinterpret_cast<f32x4 *>(at32(a.out, (row << 8) + 64u * o + 16u * (unsigned)g)) = res;
+      }
+    }
+  }
+}
+
 // b: enc2 = mlp_conv_xyz_2(geo'); w = softmax_k(mlp3_convs([enc2 | centre feat | gathered first]));
 //    out = sum_k w * gathered first.  Candidates = the frame-1 points themselves (N == S).
 template <int CB, int KP, int P, int W>
@@ -749,7 +827,13 @@ extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const flo
     check_launch("cv_fused_a2");
     return;
   }
-  if (kp == 6 && t6 <= 2048)   // coarse level: 4-wave workgroups reach twice as many CUs
+  static const int lane6 = fl_tuning("PWCLO_LANE6", 1);
+  static bool attrl = false;
+  const long long t16 = (long long)b * ((s + 15) / 16);
+  // in-lane softmax for the large levels; a coarse level has too few 16-query tiles to fill the chip (measured:
+  // 48 us against 31 us for the dense-6 kernel on 4-wave workgroups at S = 256)
+  if (kp == 6 && lane6 && t16 > 1024) launch_persistent<8>(cv_a2_lane6_kernel<8>, attrl, lds, t16, a);
+  else if (kp == 6 && t6 <= 2048)   // coarse level: 4-wave workgroups reach twice as many CUs
     launch_persistent<4>(cv_a2_dense6_kernel<4>, attr6s, lds, t6, a);
   else if (kp == 6) launch_persistent<8>(cv_a2_dense6_kernel<8>, attr6, lds, t6, a);
   else if (kp == 32) launch_persistent<8>(cv_a2_kernel<32, 2, 8>, attr32, lds, tiles_of(b, s, 32, 2), a);

@@ -59,6 +59,9 @@ def _kname(name, split_capable=True):
 
 
 def _a2_kernel_name(kp, B, S):
+    import os
+    if kp == 6 and not bf16x3_enabled() and os.environ.get("PWCLO_LANE6", "1") != "0" and B * ((S + 15) // 16) > 1024:
+        return "cv_a2_lane6_kernel<8>"
     if kp == 6:
         return _kname("cv_a2_dense6_kernel<%d>" % (8 if B * ((S + 7) // 8) > 2048 else 4))
     return _kname({32: "cv_a2_kernel<32, 2, 8>", 16: "cv_a2_kernel<16, 1, 16>", 8: "cv_a2_kernel<8, 1, 16>"}[kp],

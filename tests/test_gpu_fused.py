@@ -97,7 +97,8 @@ def test_fused_set_upconv(cuda, c2, n2, n1, hoist):
 
 @pytest.mark.parametrize("nq,ns,c,s,n", [(32, 4, 64, 256, 256), (6, 4, 64, 256, 256), (6, 4, 32, 512, 512),
                                           (6, 4, 16, 301, 280), (32, 4, 64, 70, 90), (6, 4, 32, 5, 9),
-                                          (8, 4, 64, 37, 64)])
+                                          (8, 4, 64, 37, 64),
+                                          (6, 4, 16, 8203, 8190)])   # > 1024 16-query tiles: the in-lane K = 6 kernel
 @pytest.mark.parametrize("hoist", [False, True])
 def test_fused_cost_volume(cuda, nq, ns, c, s, n, hoist):
     name = "cost_volume"
