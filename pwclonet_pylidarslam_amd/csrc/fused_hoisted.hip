@@ -240,6 +240,65 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
   }
 }
 
+// Set-upconv with the max over the K neighbours IN-LANE (cf. cv_a2_lane6_kernel): a wave tile = 16 consecutive
+// queries, pass k runs neighbour k of those queries as one 16-pixel block (lane j <-> query j), the pooled value is a
+// running maximum in registers -- no DPP reduction, and every lane stores its own query's row.
+template <int W>
+__global__ __launch_bounds__(W * 64) void upconv_lane_kernel(UpHArgs a) {
+  constexpr int B1 = 8, B2 = 4;
+  constexpr int W1 = layer_floats(1, B1);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  stage_weights(lds_w, a.w, W1 + layer_floats(B1, B2));
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int tiles_per_cloud = (a.S + 15) / 16;
+  const int ntiles = a.B * tiles_per_cloud;
+  for (int t = blockIdx.x * W + wave_index(); t < ntiles; t += gridDim.x * W) {
+    const int b = t / tiles_per_cloud;
+    const int q = (t - b * tiles_per_cloud) * 16 + j;
+    const bool valid = q < a.S;
+    const unsigned bN = (unsigned)b * (unsigned)a.N;
+    const unsigned row = (unsigned)b * (unsigned)a.S + (unsigned)(valid ? q : a.S - 1);
+    const float *c = at32(a.xyz2, mul24(row, 12u));
+    const float cx = c[0], cy = c[1], cz = c[2];
+    const unsigned slot0 = mul24(row, (unsigned)a.K);
+    f32x4 mx[B2];
+    auto run_pass = [&](auto first_tag, int k) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      const int nbr = *at32(a.idx, (slot0 + (unsigned)k) * 4u);
+      const unsigned src = bN + (unsigned)nbr;
+      const float *qp = at32(a.xyz1, mul24(src, 12u));
+      f32x4 in[1][1], h1[B1][1], h2[B2][1];
+      in[0][0] = diff_block_h(qp[0] - cx, qp[1] - cy, qp[2] - cz, 0.f, 0.f, 0.f, false, g);
+      const float *prow = at32(a.pre, (src << 9) + 16u * (unsigned)g);
+#pragma unroll
+      for (int o = 0; o < B1; ++o) h1[o][0] = ld4(prow + 16 * o);
+      mlp_layer_init<1, B1, 1, true, 1>(h1, in, lds_w, lane, [&](int o, int) { return h1[o][0]; });
+      mlp_layer<B1, B2, 1, false>(h2, h1, lds_w + W1, lane);       // ReLU after the pool
+#pragma unroll
+      for (int o = 0; o < B2; ++o) {
+        if (FIRST) {
+          mx[o] = h2[o][0];
+        } else {
+          mx[o].x = max_bits(mx[o].x, h2[o][0].x); mx[o].y = max_bits(mx[o].y, h2[o][0].y);
+          mx[o].z = max_bits(mx[o].z, h2[o][0].z); mx[o].w = max_bits(mx[o].w, h2[o][0].w);
+        }
+      }
+    };
+    run_pass(std::true_type{}, 0);
+#pragma unroll 1
+    for (int k = 1; k < a.K; ++k) run_pass(std::false_type{}, k);
+    if (valid) {
+#pragma unroll
+      for (int o = 0; o < B2; ++o) {
+        f32x4 v = mx[o];
+        v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+        *reinterpret_cast<f32x4 *>(at32(a.out, (row << 8) + 64u * o + 16u * (unsigned)g)) = v;
+      }
+    }
+  }
+}
+
 // ---- cost volume a1 / b, hoisted ------------------------------------------------------------------------
 struct CVHArgs {
   const float *xyz1;    // (B,S,3) queries
@@ -459,7 +518,11 @@ extern "C" void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const 
   static bool attr = false, attr3 = false;
   constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4));
   constexpr int lds3 = 4 * (layer_floats(1, 8) + layer_floats_bf3(8, 4));
+  static const int lane_up = fh_tuning("PWCLO_LANE_UP", 1);
+  static bool attrl = false;
+  const long long t16 = (long long)b * ((s + 15) / 16);
   if (bf16x3_enabled()) launch_h<16>(upconv_h_kernel<8, 1, 16, true>, attr3, lds3, tiles_h(b, s, 8, 1), a);
+  else if (lane_up && t16 > 2048) launch_h<16>(upconv_lane_kernel<16>, attrl, lds, t16, a);   // in-lane max over K
   else launch_h<16>(upconv_h_kernel<8, 1, 16>, attr, lds, tiles_h(b, s, 8, 1), a);
   check_launch("upconv_fused_h");
 }

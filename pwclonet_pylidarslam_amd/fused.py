@@ -9,6 +9,7 @@ BatchNorm folded into the 1x1 convolution) and ``phys`` maps the kernel's physic
 channel order (16-channel blocks, one source per block) to the layer's original input channels.
 """
 import contextlib
+import os
 
 import torch
 
@@ -498,7 +499,8 @@ class FusedUpconvHoisted:
         B, S, _ = xyz2.shape
         N, K = xyz1.shape[1], idx.shape[2]
         pooled = torch.empty((B, S, 64), dtype=torch.float32, device=xyz2.device)
-        _lib.annotate(family="mlp", kernel=_kname("upconv_h_kernel<8, 1, 16>"), flops=2.0 * B * S * K * (self.macs - 64 * 128),
+        lane = (not bf16x3_enabled() and os.environ.get("PWCLO_LANE_UP", "1") != "0" and B * ((S + 15) // 16) > 2048)
+        _lib.annotate(family="mlp", kernel="upconv_lane_kernel<16>" if lane else _kname("upconv_h_kernel<8, 1, 16>"), flops=2.0 * B * S * K * (self.macs - 64 * 128),
                       bytes=4.0 * B * (S * K * (1 + 3 + 128) + 3 * S + 64 * S))
         _lib.call("upconv_fused_h_kernel_wrapper", xyz2.device, B, N, S, K, _p(xyz2), _p(xyz1), _p(pre),
                   _p(idx), _p(self.packed), _p(pooled))

@@ -74,7 +74,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 pm = lambda t: t.permute(0, 2, 1).contiguous()      # (B,C,N) <-> (B,N,C)
 
 
-@pytest.mark.parametrize("c2,n2,n1", [(32, 512, 128), (16, 333, 90), (64, 256, 64)])
+@pytest.mark.parametrize("c2,n2,n1", [(32, 512, 128), (16, 333, 90), (64, 256, 64),
+                                      (16, 16403, 700)])    # > 2048 16-query tiles: the in-lane max-over-K kernel
 @pytest.mark.parametrize("hoist", [False, True])
 def test_fused_set_upconv(cuda, c2, n2, n1, hoist):
     name = "pose_warp_refinement_2.setupconv_features"
