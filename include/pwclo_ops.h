@@ -48,6 +48,11 @@ const char *pwclo_last_error_message(void);
 void pwclo_clear_error(void);
 
 #define PWCLO_EINVAL 10001  /* argument outside what the kernels support (message says which) */
+/* Reported by a RUNNING kernel (not at launch): the cooperative large-cloud sampler gave up waiting for a
+ * peer workgroup.  Kernels post such codes into a pinned word the library owns; pwclo_last_error() reads it
+ * without a HIP call, so it becomes visible once the kernel has run: at the next library call, or when the
+ * host calls pwclo_last_error() after synchronising the stream.  The outputs of that call are invalid. */
+#define PWCLO_ECOOP_TIMEOUT 10002
 
 /* ---- 1. the nine reference launchers ------------------------------------------------------ */
 

@@ -63,10 +63,12 @@ def set_abstraction(sd, prefix, npoint, nsample, xyz, features, taps=None, tap=N
     return new_xyz, new_features
 
 
-def set_upconv(sd, prefix, nsample, xyz2, xyz1, features2, features1):
+def set_upconv(sd, prefix, nsample, xyz2, xyz1, features2, features1, taps=None, tap=None):
     """P2/pointnet2_modules.py:479-515 (PointnetFPModulePWCLONet.forward, knn=True branch).
     Propagates features1 (B,C1,N1) at xyz1 (B,N1,3) onto xyz2 (B,N2,3)."""
     idx = knn_idx(nsample, xyz1, xyz2)
+    if taps is not None and tap:
+        taps[tap + ".idx"] = idx
     x = ops.group_points(features1.contiguous(), idx)
     grouped_xyz = ops.group_points(xyz1.transpose(1, 2).contiguous(), idx)
     xyz_diff = grouped_xyz - xyz2.transpose(1, 2).unsqueeze(-1)
@@ -183,7 +185,7 @@ def pose_warp_refinement(sd, prefix, last, xyz_f1, points_f1, xyz_f2, points_f2,
     xyz_prev_t = xyz_f1_prev.permute(0, 2, 1).contiguous()
 
     up_feat = set_upconv(sd, prefix + ".setupconv_features", 8, xyz_f1_t, xyz_prev_t, points_f1,
-                         points_f1_prev)
+                         points_f1_prev, taps, tap + ".up" if tap else None)
     up_mask = set_upconv(sd, prefix + ".setupconv_mask", 8, xyz_f1_t, xyz_prev_t, points_f1,
                          mask_prev)
     warped = warp(xyz_f1, q_coarse, t_coarse)

@@ -95,6 +95,15 @@ def check(what):
         raise RuntimeError("%s failed (error %d): %s" % (what, code, msg))
 
 
+def synchronize(device=None):
+    """Wait for the device and raise if a kernel that has run reported a device-side failure (e.g. the
+    cooperative large-cloud sampler timing out: PWCLO_ECOOP_TIMEOUT).  Launches are asynchronous, so such a
+    failure surfaces at the next library call made after the kernel ran, or here."""
+    load()
+    torch.cuda.synchronize(device)
+    check("device-side check after synchronize")
+
+
 # Optional launch profiler (bench.py / tools): an object with .add(name, meta, start_evt, end_evt).
 # Wrappers describe the next launch's algorithmic work with annotate(); both are no-ops otherwise.
 profiler = None

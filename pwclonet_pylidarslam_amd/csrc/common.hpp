@@ -14,6 +14,9 @@ constexpr int WAVE = 64;
 hipStream_t current_stream();
 void set_error(int code, const char *fmt, ...);
 bool check_launch(const char *what);  // hipGetLastError() -> sticky error; true when OK
+// Device view of the library's pinned error word (state.hip): a kernel stores a PWCLO_E* code there with a
+// system-scope atomic; pwclo_last_error() picks it up.  nullptr (and a sticky error) if it cannot be allocated.
+unsigned *device_error_word();
 
 // Argument guard used by the launchers: records PWCLO_EINVAL and makes the launcher return.
 #define PWCLO_REQUIRE(cond, ...)                      \

@@ -362,16 +362,22 @@ __device__ __forceinline__ void coop_post(unsigned long long *w, unsigned payloa
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// `spin_limit` bounds every poll loop; on expiry the workgroup raises the workspace's error word (so its peers
+// stop too), posts PWCLO_ECOOP_TIMEOUT into the library's pinned error word `host_err` (state.hip) and ends.
+// `holdback` (debug, PWCLO_FPS_COOP_DEBUG_TIMEOUT=1): the last workgroup of every cloud exits at once, which
+// is what a non-resident peer looks like to the others -- used by the test of the failure path.
 template <int I>
 __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, int log2bs, int G,
                                                           const float *__restrict__ dataset,
                                                           unsigned long long *__restrict__ ws,
                                                           int *__restrict__ idxs,
-                                                          float *__restrict__ new_xyz) {
+                                                          float *__restrict__ new_xyz, int spin_limit,
+                                                          int holdback, unsigned *host_err) {
   __shared__ unsigned long long slots[3];
   __shared__ unsigned long long bcast;      // winning key, ~0 = timed out
   __shared__ float bxyz[3];                 // its coordinates
   const int g = blockIdx.x, cloud = blockIdx.y;
+  if (holdback && g == G - 1) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int vtid = g * COOP_T + tid, ttotal = G * COOP_T;
   const float *pts = dataset + (size_t)cloud * n * 3;
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
       const unsigned long long *qs = gws + ((size_t)(it & 1) * COOP_MAX_G + lane) * COOP_SLOT_WORDS;
       unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull, w3 = 0ull, w4 = 0ull;
       bool done = false;
-      for (int spin = 0; spin < (1 << 21); ++spin) {
+      for (int spin = 0; spin < spin_limit; ++spin) {
         bool ready = true;
         if (lane < G) {
           w0 = __hip_atomic_load(qs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -478,6 +484,8 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
       if (lane == 0) {
         if (!done) {
           __hip_atomic_store(errw, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (host_err)
+            __hip_atomic_store(host_err, (unsigned)PWCLO_ECOOP_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           bcast = ~0ull;
         } else {
           bcast = vmax == 0u ? 0ull : (((unsigned long long)vmax << 32) | (unsigned long long)lmax);
@@ -628,14 +636,45 @@ static void fps_dispatch(int b, int n, int m, const float *dataset, float *temp,
     // cooperative multi-workgroup sampler; `temp` doubles as its (re-zeroed) exchange workspace
     unsigned long long *ws = reinterpret_cast<unsigned long long *>(temp);
     hipStream_t st = current_stream();
+    unsigned *host_err = device_error_word();            // a timeout inside the kernel reaches pwclo_last_error()
+    if (host_err == nullptr) return;
+    const char *dbg = getenv("PWCLO_FPS_COOP_DEBUG_TIMEOUT");   // test hook of the failure path (read per call)
+    int holdback = dbg ? atoi(dbg) : 0;
+    int spin_limit = holdback ? 256 : (1 << 21);
     hipLaunchKernelGGL(fps_coop_init_kernel, dim3(ceil_div(b * COOP_WS_WORDS, 256)), dim3(256), 0, st, ws,
                        b * COOP_WS_WORDS);
-    const int per_launch = 224 / G;                      // all workgroups of a launch must be co-resident
+    // All G workgroups of a cloud must be resident together.  hipLaunchCooperativeKernel makes the runtime
+    // guarantee exactly that (the launch is REJECTED if the grid cannot be co-resident, and the grid is
+    // dispatched as a whole even when other streams hold CUs); a stream under graph capture cannot take a
+    // cooperative launch, there the plain launch with the 224-workgroup cap is used and the bounded spins +
+    // error word are the safety net.  PWCLO_FPS_COOP_LAUNCH=0 forces the plain launch.
+    static int coop_launch = -1;
+    if (coop_launch < 0) { const char *e = getenv("PWCLO_FPS_COOP_LAUNCH"); coop_launch = e ? atoi(e) : 1; }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    const bool use_coop_api = coop_launch && cap == hipStreamCaptureStatusNone;
+    const int per_launch = 224 / G;
     for (int c0 = 0; c0 < b; c0 += per_launch) {
       const int nb = min(per_launch, b - c0);
-      hipLaunchKernelGGL((fps_coop_kernel<16>), dim3(G, nb), dim3(COOP_T), 0, st, n, m, bs, log2bs, G,
-                         dataset + (size_t)c0 * n * 3, ws + (size_t)c0 * COOP_WS_WORDS, idxs + (size_t)c0 * m,
-                         new_xyz ? new_xyz + (size_t)c0 * m * 3 : nullptr);
+      const float *d0 = dataset + (size_t)c0 * n * 3;
+      unsigned long long *w0 = ws + (size_t)c0 * COOP_WS_WORDS;
+      int *i0 = idxs + (size_t)c0 * m;
+      float *x0 = new_xyz ? new_xyz + (size_t)c0 * m * 3 : nullptr;
+      if (use_coop_api) {
+        int nv = n, mv = m, bsv = bs, lbv = log2bs, Gv = G;
+        void *args[] = {&nv, &mv, &bsv, &lbv, &Gv, &d0, &w0, &i0, &x0, &spin_limit, &holdback, &host_err};
+        hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(fps_coop_kernel<16>), dim3(G, nb),
+                                                  dim3(COOP_T), args, 0, st);
+        if (e != hipSuccess) {
+          (void)hipGetLastError();
+          set_error((int)e, "furthest_point_sampling(coop): cooperative launch of %d x %d workgroups rejected: %s",
+                    G, nb, hipGetErrorString(e));
+          return;
+        }
+      } else {
+        hipLaunchKernelGGL((fps_coop_kernel<16>), dim3(G, nb), dim3(COOP_T), 0, st, n, m, bs, log2bs, G, d0, w0, i0,
+                           x0, spin_limit, holdback, host_err);
+      }
     }
     check_launch("furthest_point_sampling(coop)");
     return;

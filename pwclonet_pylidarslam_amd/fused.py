@@ -291,9 +291,9 @@ class FusedCostVolume:
         self.macs_a2 = stack_macs(module.mlp_conv_xyz_1) + stack_macs(module.mlp2_convs)
         self.macs_b = stack_macs(module.mlp_conv_xyz_2) + stack_macs(module.mlp3_convs)
 
-    def __call__(self, xyz1, feat1, xyz2, feat2, idx_q=None, idx=None):
+    def __call__(self, xyz1, feat1, xyz2, feat2, idx_q=None, idx=None, taps=None, tap=""):
         """xyz1 (B,S,3) (warped) frame-1 points, feat1 (B,S,C), xyz2 (B,N,3), feat2 (B,N,C),
-        all point-major -> (B,S,64)."""
+        all point-major -> (B,S,64).  ``taps``: dict that receives the two neighbour lists."""
         B, S, _ = xyz1.shape
         N = xyz2.shape[1]
         dev = xyz1.device
@@ -315,6 +315,8 @@ class FusedCostVolume:
                   _p(self.w_a2), _p(pix), _p(first))
         if idx is None:
             idx = knn(k, xyz1, xyz1)
+        if taps is not None:
+            taps[tap + ".idx_q"], taps[tap + ".idx"] = idx_q, idx
         out = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
         _lib.annotate(family="mlp", flops=2.0 * B * S * k * self.macs_b,
                       bytes=4.0 * B * (S * k * (1 + 3 + 64) + S * (3 + c + 64)))
@@ -545,7 +547,7 @@ class FusedCostVolumeHoisted:
         """The three partial products that only need the inputs: u, v (first aggregate), u2."""
         return [(self.job_u, feat1), (self.job_v, feat2), (self.job_u2, feat1)]
 
-    def __call__(self, xyz1, xyz2, u, v, u2, idx_q=None, idx=None):
+    def __call__(self, xyz1, xyz2, u, v, u2, idx_q=None, idx=None, taps=None, tap=""):
         B, S, _ = xyz1.shape
         N = xyz2.shape[1]
         dev = xyz1.device
@@ -567,6 +569,8 @@ class FusedCostVolumeHoisted:
                   _p(self.w_a2), _p(pix), _p(first))
         if idx is None:
             idx = knn(k, xyz1, xyz1)
+        if taps is not None:
+            taps[tap + ".idx_q"], taps[tap + ".idx"] = idx_q, idx
         (v2,) = run_linear_jobs([(self.job_v2, first)])
         out = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
         _lib.annotate(family="mlp", kernel=_kname("cv_b_h_kernel<4, 1, %d>" % (4 if B * ((S * 4 + 15) // 16) <= 2048 else 16)),
@@ -662,8 +666,11 @@ class FusedPWCLONet:
                      head=FusedPoseHead(m.pose_calculator), last=m.last_pose_estimation)
             self.pwr.append(d)
 
-    def _refine(self, br, d, row, pose, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev):
+    def _refine(self, br, d, row, pose, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev,
+                taps=None, tap=""):
         idx_up = br.hold(knn(8, x1_prev, x1))
+        if taps is not None:
+            taps[tap + ".up.idx"] = idx_up
         if self.hoist:          # all per-point partial products of this level in one launch
             pre_f, pre_m, u, v, u2 = br.hold(*run_linear_jobs(
                 d["up_f"].jobs(emb_prev) + d["up_m"].jobs(mask_prev) + d["cv"].jobs(f1, f2)))
@@ -672,7 +679,10 @@ class FusedPWCLONet:
         with br.fork(2):        # ... and of the mask are independent of the warp -> cost-volume chain
             up_mask = br.hold(d["up_m"](x1, x1_prev, f1, pre_m if self.hoist else mask_prev, idx_up))
         warped = br.hold(quat_warp_pm(x1, q_prev, t_prev))
-        resid = br.hold(d["cv"](warped, x2, u, v, u2) if self.hoist else d["cv"](warped, f1, x2, f2))
+        if taps is not None:
+            taps[tap + ".warped"] = warped
+        resid = br.hold(d["cv"](warped, x2, u, v, u2, taps=taps, tap=tap + ".cv") if self.hoist else
+                        d["cv"](warped, f1, x2, f2, taps=taps, tap=tap + ".cv"))
         br.join(1)
         br.join(2)
         emb = d["pred_f"](f1, resid, up_feat)
@@ -736,10 +746,14 @@ class FusedPWCLONet:
         B, x, samples, ready, br = state["B"], state["x"], state["samples"], state["ready"], state["br"]
         f = None
         lv = []
+        # neighbour lists of every knn call (tests compare them with the oracle's); only when asked for
+        taps = {} if return_intermediates else None
         for lvl, (fsa, (npoint, nsample)) in enumerate(zip(self.sa, self.sa_cfg)):
             br.wait(ready[lvl])
             new_x = samples[lvl]
             idx = br.hold(knn(nsample, x, new_x))
+            if taps is not None:
+                taps["psa_%d.knn_idx" % (lvl + 1)] = idx
             if self.hoist:
                 pre = br.hold(run_linear_jobs(fsa.jobs(f))[0]) if f is not None else None
                 f = br.hold(fsa(x, new_x, pre, idx))
@@ -751,22 +765,29 @@ class FusedPWCLONet:
         (x21, f21), (x22, f22), (x23, f23), _ = [(a[B:], b[B:]) for a, b in lv]
 
         # flow_feature_encoding samples the same cloud as psa_4(frame 1): reuse x14
+        idx_ffe = knn(self.ffe_cfg[1], x13, x14)
         if self.hoist:
-            flow = self.cv3(x13, x23, *run_linear_jobs(self.cv3.jobs(f13, f23)))
-            emb4 = self.ffe(x13, x14, run_linear_jobs(self.ffe.jobs(flow))[0], knn(self.ffe_cfg[1], x13, x14))
+            flow = self.cv3(x13, x23, *run_linear_jobs(self.cv3.jobs(f13, f23)), taps=taps, tap="cv3")
+            emb4 = self.ffe(x13, x14, run_linear_jobs(self.ffe.jobs(flow))[0], idx_ffe)
         else:
-            flow = self.cv3(x13, f13, x23, f23)
-            emb4 = self.ffe(x13, x14, flow, knn(self.ffe_cfg[1], x13, x14))
+            flow = self.cv3(x13, f13, x23, f23, taps=taps, tap="cv3")
+            emb4 = self.ffe(x13, x14, flow, idx_ffe)
+        if taps is not None:
+            taps["ffe.knn_idx"] = idx_ffe
         mask4 = self.l4_pred(f14, emb4)
         pose = torch.empty((B, 4, 7), dtype=torch.float32, device=x.device)   # rows = levels 1..4
         q4, t4 = self.l4_head(emb4, mask4, pose, 3)
 
-        q3, t3, emb3, mask3 = self._refine(br, self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4)
-        q2, t2, emb2, mask2 = self._refine(br, self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3)
-        q1, t1, emb1, mask1 = self._refine(br, self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2)
+        q3, t3, emb3, mask3 = self._refine(br, self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4,
+                                           taps, "pwr3")
+        q2, t2, emb2, mask2 = self._refine(br, self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3,
+                                           taps, "pwr2")
+        q1, t1, emb1, mask1 = self._refine(br, self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2,
+                                           taps, "pwr1")
         if return_intermediates:
             return pose, dict(x11=x11, f11=f11, f13=f13, flow=flow, emb4=emb4, mask4=mask4, emb3=emb3,
-                              mask3=mask3, emb1=emb1, mask1=mask1, q=(q1, q2, q3, q4), t=(t1, t2, t3, t4))
+                              mask3=mask3, emb2=emb2, mask2=mask2, emb1=emb1, mask1=mask1, q=(q1, q2, q3, q4),
+                              t=(t1, t2, t3, t4), lists=taps)
         return pose
 
     @torch.no_grad()

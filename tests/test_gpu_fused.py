@@ -25,6 +25,15 @@ def close(a, b, rel=1e-5):
         (a - b).abs().max().item(), b.abs().max().item(), int(bad.sum()), bad.numel())
 
 
+def pose_close(pose, ref, what=""):
+    """The contract's end-to-end bar (BASELINE.json north_star: 1e-5 relative for se3 poses):
+    |pose - ref| <= 1e-5 * max|ref| + 1e-6.  Prints the measured figure (pytest -s)."""
+    pose, ref = pose.detach().cpu().double(), ref.detach().cpu().double()
+    err, scale = (pose - ref).abs().max().item(), ref.abs().max().item()
+    print("\n%s: max |pose - ref| = %.3e, max |ref| = %.3f, ratio %.2e" % (what or "pose", err, scale, err / scale))
+    assert err <= 1e-5 * scale + 1e-6, "%s: |pose - ref| = %.3e exceeds 1e-5 * %.3f + 1e-6" % (what, err, scale)
+
+
 def filled(module, prefix):
     sd = module.state_dict()
     for k, v in sd.items():
@@ -119,7 +128,7 @@ def test_fused_cost_volume(cuda, nq, ns, c, s, n, hoist):
         cv = fused.FusedCostVolume(mod.to(cuda))
         out = cv(pm(x1).to(cuda), pm(p1).to(cuda), pm(x2).to(cuda), pm(p2).to(cuda),
                  idx_q=taps["cv.idx_q"].to(cuda), idx=taps["cv.idx"].to(cuda))
-    close(pm(out), ref, rel=2e-5)
+    close(pm(out), ref)
 
 
 def test_fused_pointwise_and_pose_head(cuda):
@@ -191,16 +200,15 @@ def test_fused_network_against_reference_golden(cuda, case, hoist, monkeypatch):
     assert fnet.hoist == (hoist == "1")
     pose, inter = fnet(x1, x2, return_intermediates=True)
     ref = torch.from_numpy(z["pose_params"])
-    err = (pose.cpu() - ref).abs().max().item()
-    assert err < 1e-4, err
+    pose_close(pose, ref, "fused %s hoist=%s vs reference golden" % (case, hoist))
     # level-1 sampled coordinates are exact, level-3 features match the reference's tap
     assert torch.equal(inter["x11"].cpu(), torch.from_numpy(z["f1.psa_1.new_xyz"]))
-    close(pm(inter["f13"]), torch.from_numpy(z["f1.psa_3.new_features"]), rel=2e-5)
-    close(pm(inter["flow"]), torch.from_numpy(z["cv3.out"]), rel=5e-5)
+    close(pm(inter["f13"]), torch.from_numpy(z["f1.psa_3.new_features"]))
+    close(pm(inter["flow"]), torch.from_numpy(z["cv3.out"]))
     # and the unfused module path agrees with the fused one
     with torch.no_grad():
         eager, _ = net(x1, None, x2, None)
-    torch.testing.assert_close(pose, eager, rtol=0, atol=5e-5)
+    pose_close(pose, eager, "fused vs module path")
 
 
 def test_fused_forward_is_bitwise_deterministic_and_graph_safe(cuda):
@@ -210,7 +218,10 @@ def test_fused_forward_is_bitwise_deterministic_and_graph_safe(cuda):
     pc1, pc2, _, _ = synthetic.kitti_like_pair(41, 4096, 3)
     x1 = torch.from_numpy(pc1[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
     x2 = torch.from_numpy(pc2[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
-    net = _net(cuda).prepare_fused()
+    net = _net(cuda)
+    with torch.no_grad():
+        module_before, _ = net(x1, None, x2, None)            # module path, before any packing
+    net.prepare_fused()
     with torch.no_grad():
         a, _ = net(x1, None, x2, None)
         b, _ = net(x1, None, x2, None)
@@ -240,14 +251,16 @@ def test_fused_forward_is_bitwise_deterministic_and_graph_safe(cuda):
     staged.wait_all()
     for o, _slot in outs[-3:]:
         assert torch.equal(o, a)
-    # train() drops the packed weights; the unfused module path then agrees within fp32 noise
+    # train() drops the packed weights: eval() afterwards runs the module path again, parameters untouched
+    # (compared with the module path's own earlier result -- against the fused result a pair may sit on a
+    # near-tie neighbour flip, which tests/test_gpu_config2.py treats properly)
     net.train()
     assert net._fused is None
     net.eval()
     net.log_mode = "device"
     with torch.no_grad():
         c, log = net(x1, None, x2, None)
-    torch.testing.assert_close(c, a, rtol=0, atol=5e-5)
+    pose_close(c, module_before, "module path after train()/eval() vs module path before packing")
     assert log["embedding_mask"].shape == (3, 2048)
     _, lazy = net.prepare_fused()(x1, None, x2, None)      # fused path: same values, built on access
     torch.testing.assert_close(lazy["embedding_mask"], log["embedding_mask"], rtol=1e-4, atol=1e-6)
@@ -281,7 +294,7 @@ def test_prediction_module_adapter_matches_forward(cuda):
         got_fused, log = mod({"numpy_pc_0": f1, "numpy_pc_1": f2})
     assert torch.equal(got_fused, ref_fused)
     assert torch.equal(log["point_cloud"], ref_log["point_cloud"])
-    torch.testing.assert_close(got_fused, ref_module, rtol=0, atol=5e-5)
+    pose_close(got_fused, ref_module, "adapter fused vs module route")
 
 
 def test_fps_chain_prefix_certificate(cuda):
@@ -342,8 +355,8 @@ def test_fps_chain_matches_full_samplers_on_many_clouds(cuda):
 def test_bf16x3_split_path_matches_golden(cuda, case, monkeypatch):
     """PWCLO_BF16X3=1 (opt-in): the stack layers with an even number of input blocks run as three-term bf16
     splits on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Same bounds as the fp32-MFMA path: pose
-    within 1e-4 of the reference's golden output, level-3 features / cost volume within 2e-5 / 5e-5, and
-    within 2e-6 of the fp32-MFMA path itself."""
+    within the 1e-5 contract of the reference's golden output, level-3 features / cost volume within the layer
+    bound, and within 2e-6 of the fp32-MFMA path itself."""
     z = np.load(os.path.join(GOLDEN, "pwclonet_%s.npz" % case))
     meta = json.loads(str(z["meta"]))
     if meta["generator"] == "uniform":
@@ -357,8 +370,8 @@ def test_bf16x3_split_path_matches_golden(cuda, case, monkeypatch):
     monkeypatch.setenv("PWCLO_BF16X3", "1")
     pose, inter = fused.FusedPWCLONet(net)(x1, x2, return_intermediates=True)     # packs and launches the split format
     ref = torch.from_numpy(z["pose_params"])
-    assert (pose.cpu() - ref).abs().max().item() < 1e-4
-    close(pm(inter["f13"]), torch.from_numpy(z["f1.psa_3.new_features"]), rel=2e-5)
-    close(pm(inter["flow"]), torch.from_numpy(z["cv3.out"]), rel=5e-5)
+    pose_close(pose, ref, "bf16x3 %s vs reference golden" % case)
+    close(pm(inter["f13"]), torch.from_numpy(z["f1.psa_3.new_features"]))
+    close(pm(inter["flow"]), torch.from_numpy(z["cv3.out"]))
     assert (pose - pose32).abs().max().item() < 2e-6
     assert not torch.equal(inter["flow"], inter32["flow"])                        # it really is the other arithmetic

@@ -92,19 +92,51 @@ def test_fps_batch16_ties_and_padding(cuda):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("b,n,m,lattice", [(3, 30000, 150, False), (2, 40001, 120, True), (9, 25000, 40, False)])
+@pytest.mark.parametrize("b,n,m,lattice", [(3, 30000, 150, 0), (2, 40001, 120, 9), (9, 25000, 40, 0),
+                                           # BASELINE configs[4] at its real size (G = 8 workgroups per cloud, 8191
+                                           # alternations of the two exchange slot sets): random, a lattice with
+                                           # exact ties at every decision, and a lattice with fewer distinct points
+                                           # than samples (19^3 = 6859 < 8192: exhaustion, distance-0 ties)
+                                           (1, 120000, 8192, 0), (1, 120000, 8192, 30), (1, 120000, 8192, 9)])
 def test_fps_large_cloud_cooperative(cuda, b, n, m, lattice):
     """n > 24576: several workgroups share a cloud and exchange their arg-max through global memory
     (csrc/sampling.hip: fps_coop_kernel); same indices as the oracle, ties and zero padding included."""
     gen = torch.Generator().manual_seed(n + m)
     if lattice:
-        x = torch.randint(-9, 10, (b, n, 3), generator=gen).float()
+        x = torch.randint(-lattice, lattice + 1, (b, n, 3), generator=gen).float()
     else:
         x = (torch.rand(b, n, 3, generator=gen) * 2 - 1) * 40
     x[0, 100:5000] = 0.0
     ref = O.furthest_point_sampling(x, m)
     out = E.furthest_point_sampling(g(x, cuda), m).cpu()
     assert torch.equal(out, ref)
+
+
+def test_fps_cooperative_timeout_is_reported(cuda, monkeypatch):
+    """The cooperative sampler must never continue silently (reference contract: cuda_utils.h:30-39 exits).
+    PWCLO_FPS_COOP_DEBUG_TIMEOUT=1 shrinks the spin bound and makes the last workgroup of each cloud leave at
+    once -- what a non-resident peer looks like; the others give up, the kernel posts PWCLO_ECOOP_TIMEOUT into
+    the library's pinned error word and the host raises at the next check.  Run once."""
+    from pwclonet_pylidarslam_amd import _lib
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(1, 40000, 3, generator=gen) * 2 - 1) * 40
+    xg = g(x, cuda)
+    monkeypatch.setenv("PWCLO_FPS_COOP_DEBUG_TIMEOUT", "1")
+    E.furthest_point_sampling(xg, 64)                       # the launch itself succeeds (asynchronous)
+    monkeypatch.delenv("PWCLO_FPS_COOP_DEBUG_TIMEOUT")
+    with pytest.raises(RuntimeError, match="co-resident"):
+        _lib.synchronize(cuda)
+    torch.cuda.synchronize()
+    _lib.synchronize(cuda)                                   # reported once, then clear
+    out = E.furthest_point_sampling(xg, 64).cpu()            # and the library keeps working
+    assert torch.equal(out, O.furthest_point_sampling(x, 64))
+    # the same failure also surfaces at the next library CALL made after the kernel ran
+    monkeypatch.setenv("PWCLO_FPS_COOP_DEBUG_TIMEOUT", "1")
+    E.furthest_point_sampling(xg, 64)
+    monkeypatch.delenv("PWCLO_FPS_COOP_DEBUG_TIMEOUT")
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="co-resident"):
+        E.gather_points(g(torch.zeros(1, 3, 8), cuda), g(torch.zeros(1, 4, dtype=torch.int32), cuda))
 
 
 # ---------------------------------------------------------------- gather / group (+ grads)
