@@ -5,14 +5,19 @@ batch 32 per GPU, fp32, eval mode (BASELINE.json metric, configs[2]).
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  A step = one forward over one batch of 32 synthetic frame pairs already
+One process per GPU.  Started WITHOUT torchrun and with --gpus N > 1, the process only supervises: before
+making any GPU call it starts N fresh rank processes of itself (dist_util.spawn_ranks) and exits with their
+code; rank 0 of those prints the line.  A step = one forward over one batch of 32 synthetic frame pairs already
 resident in HBM.  The forward has no cross-rank exchange (independent frame pairs), so the ranks
 are replicas ("weak" scaling); the only collectives are the barrier around the timed region and
 the MAX-reduce of its duration.  Rank 0 prints ONE JSON line.
 
 Timed region: W warm-up steps, then exactly K steps between two fences (device sync + barrier +
-device sync).  By default a step is one hipGraph replay and four batches are kept in flight
-(`--inflight 4`, each a forward over its own batch of 32; DESIGN.md "Launch structure").
+device sync), MAX over ranks.  The region is repeated `--repeats` R times back to back (each repeat again
+exactly K steps between fences); `value` / `ms_per_step` are the MEDIAN repeat, `repeats` lists min / median /
+max (the GPU is busy for R*K steps, so an outside sampler sees the work).  By default a step is one hipGraph
+replay and four batches are kept in flight (`--inflight 4`, each a forward over its own batch of 32; DESIGN.md
+"Launch structure").
 
 `roofline`: after the timed region the same step runs three more times eagerly with HIP events
 around every launch of the library (events recorded on the launch stream); the object reports the
@@ -32,7 +37,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import pwclonet_pylidarslam_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime starts)
+import pwclonet_pylidarslam_amd  # noqa: E402
+
+pwclonet_pylidarslam_amd.configure_hw_queues(8)   # explicit, before the first HIP call: 4 batches in flight need > 4 queues
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -185,21 +192,34 @@ def roofline_objects(fam):
     return roof, kernels
 
 
-def cpu_baseline(net, npoints, pairs):
-    """The CPU oracle (restatement of the reference path, bit-identical to the imported reference
-    in the build container) on `pairs` sequential B=1 2xN pairs.  A baseline, not a target."""
-    from oracle import model as omodel
+def cpu_baseline(net, npoints, timed=5):
+    """the CPU oracle (restatement of the reference path, pinned bit-identically to the
+    imported reference in the build container) on the same KITTI-shaped pairs, batch 1 and batch 4, eval mode,
+    fp32, 1 warm-up + `timed` (>= 3) forwards each, MEDIAN reported.  All host cores are used: torch's CPU
+    convolutions with its default intra-op threads, the C ops' FPS (over clouds) and knn (over queries) loops
+    with OpenMP.  `value` is the better of the two batch sizes.  A baseline, not a target."""
+    from oracle import model as omodel, ops as oops
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-    x1, x2 = make_batch(pairs, npoints, 999, torch.device("cpu"))
-    omodel.pwclonet_forward(sd, x1[:1], x2[:1])  # warm-up
-    t0 = time.perf_counter()
-    for i in range(pairs):
-        omodel.pwclonet_forward(sd, x1[i:i + 1], x2[i:i + 1])
-    dt = time.perf_counter() - t0
-    return {"value": pairs / dt, "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d sequential B=1 2x%d-pt pairs through oracle.model: torch CPU convolutions on %d "
-                      "threads, C extension ops and knn single-threaded (%.1f s)"
-                      % (pairs, npoints, torch.get_num_threads(), dt)}
+    x1, x2 = make_batch(4, npoints, 999, torch.device("cpu"))
+    rows, t_all = {}, time.perf_counter()
+    for bsz in (1, 4):
+        omodel.pwclonet_forward(sd, x1[:bsz], x2[:bsz])  # warm-up
+        ts = []
+        for _ in range(max(3, timed)):
+            t0 = time.perf_counter()
+            omodel.pwclonet_forward(sd, x1[:bsz], x2[:bsz])
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        rows["batch%d" % bsz] = {"median_s_per_forward": ts[len(ts) // 2], "min_s": ts[0], "max_s": ts[-1],
+                                 "pairs_per_s": bsz / ts[len(ts) // 2], "timed_forwards": len(ts)}
+    best = max(rows.values(), key=lambda r: r["pairs_per_s"])
+    return {"value": best["pairs_per_s"], "unit": "frame-pairs/s", "cores": os.cpu_count(), "kind": "port",
+            "torch_threads": torch.get_num_threads(), "c_ops_threads": oops.num_threads(), **rows,
+            "sample": "oracle.model on 2x%d-pt pairs: batch 1 and batch 4, 1 warm-up + %d timed forwards each, median; "
+                      "os.cpu_count() = %d, torch.get_num_threads() = %d, C ops (FPS over clouds, knn over queries) on "
+                      "%d OpenMP threads; %.1f s of CPU work in total"
+                      % (npoints, max(3, timed), os.cpu_count(), torch.get_num_threads(), oops.num_threads(),
+                         time.perf_counter() - t_all)}
 
 
 def bf16x3_variant(args, dev, x1, x2, pose_ref, streams):
@@ -231,11 +251,50 @@ def bf16x3_variant(args, dev, x1, x2, pose_ref, streams):
                     "level-1 neighbour list differs between the two paths after the warp (DESIGN.md section 2)"}
 
 
+def step_roofline(fam, ms_per_step):
+    """Step-level figures: every MFMA-stack launch's algorithmic FLOP against (a) the serial sum of their
+    isolated launch times and (b) the pipelined step time the headline `value` is made of."""
+    mlp = fam.get("mlp", {"flops": 0.0, "ms": 0.0})
+    gflop = mlp["flops"] / 1e9
+    fam_tf = gflop / mlp["ms"] if mlp["ms"] > 0 else 0.0            # GFLOP / ms = TFLOP/s
+    step_tf = gflop / ms_per_step if ms_per_step > 0 else 0.0
+    return {"algorithmic_gflop_per_step": gflop, "ms_per_step": ms_per_step,
+            "achieved_tflops": step_tf, "frac": step_tf / MFMA_F32_PEAK_TFLOPS,
+            "mlp_family_serial_ms": mlp["ms"], "mlp_family_tflops": fam_tf,
+            "mlp_family_frac": fam_tf / MFMA_F32_PEAK_TFLOPS,
+            "note": "frac = all MFMA-stack FLOP of a step / the WHOLE pipelined step time (FPS, knn and glue "
+                    "included) / fp32 MFMA peak; mlp_family_frac = the same FLOP / serial sum of the stack "
+                    "kernels' isolated launch times"}
+
+
+def dry_run(args):
+    """--dry-run: the launch / rendezvous / aggregation plumbing with the GPU work replaced by a host sleep
+    (gloo, CPU).  For the CPU test of the self-spawn path; prints a line marked `dry_run`, never a result."""
+    rank, _local, world = dist_util.env_world()
+    dist_util.init("gloo")
+    dist_util.fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    dist_util.fence()
+    dt = dist_util.max_over_ranks(time.perf_counter() - t0)
+    pairs = dist_util.sum_over_ranks(args.batch * args.steps)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "plumbing only (no GPU work)", "n_gpus": world,
+                          "steps": args.steps, "global_pairs": pairs, "ms_per_step": 1e3 * dt / args.steps}),
+              flush=True)
+    dist_util.finish()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how many times the K-step timed region is run back to back (median reported); 0 = as many "
+                         "as fit in about --timed-seconds (at least 5, at most 200), decided from the first repeat")
+    ap.add_argument("--timed-seconds", type=float, default=3.0)
     ap.add_argument("--batch", type=int, default=32, help="frame pairs per GPU per step")
     ap.add_argument("--npoints", type=int, default=8192)
     ap.add_argument("--log-mode", default="host", choices=["host", "device", "none"],
@@ -253,13 +312,28 @@ def main():
                     help="reference-shaped module graph on the HIP ops (torch conv/BN) instead of the fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=16)
+    ap.add_argument("--cpu-forwards", type=int, default=5, help="timed CPU forwards per batch size (>= 3)")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra (untimed-region) measurement of the opt-in bf16x3 split path")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing only: rendezvous + fences + aggregation over gloo with a host sleep as the step")
     args = ap.parse_args()
 
+    if args.gpus > 1 and not dist_util.launched_by_torchrun():
+        # The driver's `python bench.py --gpus N`: this process has made no GPU call and makes none; it starts
+        # N rank processes (one per GPU) and passes their exit code on.
+        if not args.dry_run and torch.cuda.device_count() < args.gpus:   # device_count() does not initialise HIP
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, torch.cuda.device_count()))
+            sys.exit(2)
+        sys.exit(dist_util.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     rank, local_rank, world = dist_util.env_world()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d (launch with --nproc-per-node == --gpus)\n"
+                         % (world, args.gpus))
+        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist_util.init("nccl", dev)
@@ -299,13 +373,20 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    dist_util.fence(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pose = step()
-    dist_util.fence(dev)
-    dt = dist_util.max_over_ranks(time.perf_counter() - t0, dev)
+    times, repeats = [], (args.repeats if args.repeats > 0 else 5)
+    while len(times) < repeats:
+        dist_util.fence(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pose = step()
+        dist_util.fence(dev)
+        times.append(dist_util.max_over_ranks(time.perf_counter() - t0, dev))
+        if args.repeats <= 0 and len(times) == 1:     # same decision on every rank: times[0] is the MAX over ranks
+            repeats = int(min(200, max(5, round(args.timed_seconds / max(times[0], 1e-6)))))
     assert torch.isfinite(pose).all()
+    _lib.synchronize(dev)             # raises if any kernel reported a device-side failure
+    ordered = sorted(times)
+    dt = ordered[len(ordered) // 2]   # median repeat
 
     if rank == 0:
         out = {
@@ -314,6 +395,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": {"n": len(times), "reported": "median",
+                        "ms_per_step_min": 1e3 * ordered[0] / args.steps,
+                        "ms_per_step_median": 1e3 * dt / args.steps,
+                        "ms_per_step_max": 1e3 * ordered[-1] / args.steps,
+                        "ms_per_step_all": [1e3 * t / args.steps for t in times]},
             "config": {"workload": "BASELINE.json configs[2]: synthetic KITTI-shaped 2x%d-pt pairs, "
                                    "batch %d per GPU, full 4-level pyramid, eval mode, fp32"
                                    % (args.npoints, args.batch),
@@ -321,20 +407,22 @@ def main():
                        "parallelism": "replicas x%d (no forward collective)" % world,
                        "launch": args.launch, "batches_in_flight": args.inflight if pipe else 1,
                        "pipeline": (args.pipeline if pipe else "none"),
-                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "hw_queues": pwclonet_pylidarslam_amd.hw_queues(),
                        "kernels": "module graph + torch conv/BN" if args.unfused
                        else "fused gather+MFMA-MLP kernels (BN folded)",
                        "log_dict": args.log_mode + " (lazy)"},
         }
         if not args.no_roofline and not args.unfused:
-            roof, kernels = roofline_objects(instrumented_pass(net, x1, x2))
+            fam = instrumented_pass(net, x1, x2)
+            roof, kernels = roofline_objects(fam)
+            roof["step"] = step_roofline(fam, out["ms_per_step"])
             out["roofline"] = roof
             out["kernels"] = kernels
         if not args.no_variants and world == 1 and pipe is not None and not args.unfused \
                 and args.pipeline == "whole" and os.environ.get("PWCLO_BF16X3", "0") == "0":
             out["variants"] = {"bf16x3": bf16x3_variant(args, dev, x1, x2, pose.clone(), pipe.streams)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(net, args.npoints, args.cpu_pairs)
+            out["cpu_baseline"] = cpu_baseline(net, args.npoints, args.cpu_forwards)
         print(json.dumps(out), flush=True)
     dist_util.finish()
 

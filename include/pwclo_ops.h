@@ -201,17 +201,22 @@ void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int c2, int w1
 
 /* CostVolume.forward (PW/costvolume.py:63-190) in three launches.
  * a1: per (query s, neighbour k) pixel: mlp_convs([geometry10 | feat1[s] | feat2[idx]]) -> pix
- *     (b, s*kp, 64), kp = k rounded up to 8/16/32, except k == 6 (stored densely, kp = 6; a buffer of
- *     s*8 slots is always large enough).  xyz1 (b,s,3), feat1 (b,s,c), xyz2 (b,n,3), feat2 (b,n,c),
- *     idx (b,s,k).  a1 and a2 of one cost volume must be called with the same k.
+ *     (b, s*pix_slots, 64).  pix_slots is the CALLER's choice (it allocates pix) and must be passed identically
+ *     to a1 and a2: k rounded up to 8/16/32, or 6 for k == 6 (dense layout of the refinement levels).
+ *     xyz1 (b,s,3), feat1 (b,s,c), xyz2 (b,n,3), feat2 (b,n,c), idx (b,s,k).
+ * Packed-weight format (entry points that take `wfmt, packed_floats`): 0 = fp32 operand tiles
+ *     (v_mfma_f32_16x16x4_f32), 1 = the opt-in three-term bf16 split tiles (csrc/mlp_core.hpp); the format is a
+ *     property of the buffer, fixed when it was packed.  packed_floats = its length; a length that does not match
+ *     the layout the selected kernel indexes is refused with PWCLO_EINVAL (never read out of bounds).
  * a2: mlp_conv_xyz_1(geometry10), mlp2_convs, softmax over k, sum_k w*pix -> out (b,s,64).
  * b : second aggregate over the k<=4 frame-1 neighbours idx (b,s,k) of each frame-1 point:
  *     mlp_conv_xyz_2, mlp3_convs([enc | feat1[s] | first[idx]]), softmax, sum_k w*first[idx]. */
 void cv_fused_a1_kernel_wrapper(int b, int n, int s, int k, int c, const float *xyz1,
                                 const float *feat1, const float *xyz2, const float *feat2,
-                                const int *idx, const float *packed_w, float *pix);
+                                const int *idx, const float *packed_w, float *pix, int pix_slots);
 void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const float *xyz1, const float *xyz2,
-                                const int *idx, const float *packed_w, const float *pix, float *out);
+                                const int *idx, const float *packed_w, const float *pix, float *out,
+                                int pix_slots, int wfmt, int packed_floats);
 void cv_fused_b_kernel_wrapper(int b, int s, int k, int c, const float *xyz1, const float *feat1,
                                const float *first, const int *idx, const float *packed_w, float *out);
 
@@ -290,18 +295,20 @@ void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int *cin, cons
 /* sa_fused with pre (b,n,c1) = W1_feat . feat + b1 (NULL at level 0, where layer 1 is whole). */
 void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, int c2, int c3, const float *xyz,
                                const float *new_xyz, const float *pre, const int *idx,
-                               const float *packed_w, float *out);
+                               const float *packed_w, float *out, int wfmt, int packed_floats);
 /* upconv_fused with pre (b,n,128) = W1_feat . feat1 + b1. */
 void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz2, const float *xyz1,
-                                   const float *pre, const int *idx, const float *packed_w, float *out);
+                                   const float *pre, const int *idx, const float *packed_w, float *out,
+                                   int wfmt, int packed_floats);
 /* cv_fused_a1 with u (b,s,128) = W1_p . feat1 + b1 and v (b,n,128) = W1_q . feat2. */
 void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz1, const float *u,
                                   const float *xyz2, const float *v, const int *idx,
-                                  const float *packed_w, float *pix);
+                                  const float *packed_w, float *pix, int pix_slots, int wfmt,
+                                  int packed_floats);
 /* cv_fused_b with u2 (b,s,128) = W_p . feat1 + b, v2 (b,s,128) = W_f . first, first (b,s,64). */
 void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xyz1, const float *u2,
                                  const float *v2, const float *first, const int *idx,
-                                 const float *packed_w, float *out);
+                                 const float *packed_w, float *out, int wfmt, int packed_floats);
 
 #ifdef __cplusplus
 }

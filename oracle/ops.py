@@ -47,6 +47,8 @@ def lib():
         L.oracle_three_interpolate.argtypes = [_i, _i, _i, _i, _F, _I, _F, _F]
         L.oracle_three_interpolate_grad.argtypes = [_i, _i, _i, _i, _F, _I, _F, _F]
         L.oracle_knn_point.argtypes = [_i, _i, _i, _i, _F, _F, _I, _F]
+        L.oracle_num_threads.argtypes = []
+        L.oracle_num_threads.restype = _i
         _lib = L
     return _lib
 
@@ -61,6 +63,11 @@ def _n(t):
     assert t.dtype == torch.int32 and t.is_contiguous() and t.device.type == "cpu", \
         "oracle expects contiguous int32 CPU tensors"
     return ctypes.cast(t.data_ptr(), _I)
+
+
+def num_threads():
+    """Host threads the C oracle's FPS (over clouds) and knn (over queries) loops use."""
+    return lib().oracle_num_threads()
 
 
 def opt_n_threads(work_size):

@@ -50,9 +50,11 @@ void oracle_furthest_point_sampling(int b, int n, int m, const float *dataset,
                                     float *temp, int *idxs) {
   if (m <= 0) return;
   const int bs = oracle_opt_n_threads(n);
-  float *dists = (float *)malloc(sizeof(float) * (size_t)bs);
-  int *dists_i = (int *)malloc(sizeof(int) * (size_t)bs);
+  /* clouds are independent: one host thread per cloud (same results as the serial loop) */
+#pragma omp parallel for schedule(dynamic, 1)
   for (int bi = 0; bi < b; ++bi) {
+    float *dists = (float *)malloc(sizeof(float) * (size_t)bs);
+    int *dists_i = (int *)malloc(sizeof(int) * (size_t)bs);
     const float *pts = dataset + (size_t)bi * n * 3;
     float *tmp = temp + (size_t)bi * n;
     int *out = idxs + (size_t)bi * m;
@@ -94,9 +96,9 @@ void oracle_furthest_point_sampling(int b, int n, int m, const float *dataset,
       old = dists_i[0];
       out[j] = old;
     }
+    free(dists);
+    free(dists_i);
   }
-  free(dists);
-  free(dists_i);
 }
 
 /* P2/_ext-src/src/sampling_gpu.cu:8-20 : out[b,c,j] = points[b,c,idx[b,j]] */
@@ -283,11 +285,15 @@ static int knn_less(const knn_ent *a, const knn_ent *b) {
 
 void oracle_knn_point(int b, int n, int s, int nsample, const float *xyz,
                       const float *new_xyz, int *idx, float *dist) {
+  /* queries are independent: host threads share the (cloud, query) range (same results as the serial loop) */
+#pragma omp parallel
+  {
   knn_ent *heap = (knn_ent *)malloc(sizeof(knn_ent) * (size_t)nsample);
+#pragma omp for collapse(2) schedule(static)
   for (int bi = 0; bi < b; ++bi) {
-    const float *p = xyz + (size_t)bi * n * 3;
-    const float *q = new_xyz + (size_t)bi * s * 3;
     for (int j = 0; j < s; ++j) {
+      const float *p = xyz + (size_t)bi * n * 3;
+      const float *q = new_xyz + (size_t)bi * s * 3;
       const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
       int cnt = 0; /* heap[0..cnt) kept sorted ascending by (d, i) */
       for (int k = 0; k < n; ++k) {
@@ -312,4 +318,13 @@ void oracle_knn_point(int b, int n, int s, int nsample, const float *xyz,
     }
   }
   free(heap);
+  }
 }
+
+/* Host threads the parallel loops above use (1 when built without OpenMP). */
+#ifdef _OPENMP
+#include <omp.h>
+int oracle_num_threads(void) { return omp_get_max_threads(); }
+#else
+int oracle_num_threads(void) { return 1; }
+#endif

@@ -476,7 +476,7 @@ extern "C" void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int
 
 extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, int c2, int c3, const float *xyz,
                                           const float *new_xyz, const float *pre, const int *idx,
-                                          const float *packed_w, float *out) {
+                                          const float *packed_w, float *out, int wfmt, int packed_floats) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "sa_fused_h: nsample=%d outside [1,32]", k);
   PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 32)), "sa_fused_h: batch too large for 32-bit offsets (b=%d)", b);
@@ -490,7 +490,8 @@ extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, in
                              layer_floats(A2 / 16, A3 / 16));                                          \
     constexpr int lds3 = 4 * (layer_floats(1, A1 / 16) + layer_floats_any<true>(A1 / 16, A2 / 16) +    \
                               layer_floats_any<true>(A2 / 16, A3 / 16));                               \
-    if (bf16x3_enabled())                                                                             \
+    PWCLO_REQUIRE_PACKED("sa_fused_h", wfmt, packed_floats, lds / 4, lds3 / 4);                        \
+    if (wfmt == PWCLO_WFMT_BF16X3)                                                                    \
       launch_h<WW>(sa_h_kernel<A1 / 16, A2 / 16, A3 / 16, KP, PP, WW, XYZ, true>, attr3, lds3,          \
                    tiles_h(b, s, KP, PP), a);                                                         \
     else                                                                                              \
@@ -510,7 +511,7 @@ extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, in
 
 extern "C" void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz2, const float *xyz1,
                                               const float *pre, const int *idx, const float *packed_w,
-                                              float *out) {
+                                              float *out, int wfmt, int packed_floats) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 8, "upconv_fused_h: nsample=%d outside [1,8]", k);
   PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 8)), "upconv_fused_h: batch too large for 32-bit offsets (b=%d)", b);
@@ -521,7 +522,8 @@ extern "C" void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const 
   static const int lane_up = fh_tuning("PWCLO_LANE_UP", 1);
   static bool attrl = false;
   const long long t16 = (long long)b * ((s + 15) / 16);
-  if (bf16x3_enabled()) launch_h<16>(upconv_h_kernel<8, 1, 16, true>, attr3, lds3, tiles_h(b, s, 8, 1), a);
+  PWCLO_REQUIRE_PACKED("upconv_fused_h", wfmt, packed_floats, lds / 4, lds3 / 4);
+  if (wfmt == PWCLO_WFMT_BF16X3) launch_h<16>(upconv_h_kernel<8, 1, 16, true>, attr3, lds3, tiles_h(b, s, 8, 1), a);
   else if (lane_up && t16 > 2048) launch_h<16>(upconv_lane_kernel<16>, attrl, lds, t16, a);   // in-lane max over K
   else launch_h<16>(upconv_h_kernel<8, 1, 16>, attr, lds, tiles_h(b, s, 8, 1), a);
   check_launch("upconv_fused_h");
@@ -529,16 +531,19 @@ extern "C" void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const 
 
 extern "C" void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz1, const float *u,
                                              const float *xyz2, const float *v, const int *idx,
-                                             const float *packed_w, float *pix) {
+                                             const float *packed_w, float *pix, int pix_slots, int wfmt,
+                                             int packed_floats) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a1_h: nsample_q=%d outside [1,32]", k);
+  PWCLO_REQUIRE(cv_pix_slots_valid(k, pix_slots), "cv_fused_a1_h: pix_slots=%d invalid for nsample_q=%d", pix_slots, k);
   PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 32)), "cv_fused_a1_h: batch too large for 32-bit offsets (b=%d)", b);
   CVHArgs a{xyz1, u, xyz2, v, nullptr, idx, packed_w, pix, b, n, s, k};
-  const int kp = cv_pix_slots(k);
+  const int kp = pix_slots;
   constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4) + layer_floats(4, 4));
   constexpr int lds3 = 4 * (layer_floats(1, 8) + layer_floats_bf3(8, 4) + layer_floats_bf3(4, 4));
   static bool a32 = false, a16 = false, a8 = false, a6 = false, b32 = false, b16 = false, b8 = false, b6 = false;
-  if (bf16x3_enabled()) {
+  PWCLO_REQUIRE_PACKED("cv_fused_a1_h", wfmt, packed_floats, lds / 4, lds3 / 4);
+  if (wfmt == PWCLO_WFMT_BF16X3) {
     if (kp == 6) launch_h<16>(cv_a1_h_kernel<6, 1, 16, true>, b6, lds3, tiles_h(b, s, 6, 1), a);
     else if (kp == 32) launch_h<16>(cv_a1_h_kernel<32, 1, 16, true>, b32, lds3, tiles_h(b, s, 32, 1), a);
     else if (kp == 16) launch_h<16>(cv_a1_h_kernel<16, 1, 16, true>, b16, lds3, tiles_h(b, s, 16, 1), a);
@@ -555,7 +560,7 @@ extern "C" void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const f
 
 extern "C" void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xyz1, const float *u2,
                                             const float *v2, const float *first, const int *idx,
-                                            const float *packed_w, float *out) {
+                                            const float *packed_w, float *out, int wfmt, int packed_floats) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 4, "cv_fused_b_h: nsample=%d outside [1,4]", k);
   PWCLO_REQUIRE(rows_fit_32bit((long long)b * s * 4), "cv_fused_b_h: batch too large for 32-bit offsets (b=%d)", b);
@@ -565,8 +570,9 @@ extern "C" void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xy
   static bool attr_s = false, attr3 = false, attr3_s = false;
   constexpr int lds3 = 4 * (layer_floats(1, 4) + layer_floats_bf3(4, 8) + layer_floats_bf3(8, 4));
   const bool small = tiles_h(b, s, 4, 1) <= 2048;
-  if (bf16x3_enabled() && small) launch_h<4>(cv_b_h_kernel<4, 1, 4, true>, attr3_s, lds3, tiles_h(b, s, 4, 1), a);
-  else if (bf16x3_enabled()) launch_h<16>(cv_b_h_kernel<4, 1, 16, true>, attr3, lds3, tiles_h(b, s, 4, 1), a);
+  PWCLO_REQUIRE_PACKED("cv_fused_b_h", wfmt, packed_floats, lds / 4, lds3 / 4);
+  if (wfmt == PWCLO_WFMT_BF16X3 && small) launch_h<4>(cv_b_h_kernel<4, 1, 4, true>, attr3_s, lds3, tiles_h(b, s, 4, 1), a);
+  else if (wfmt == PWCLO_WFMT_BF16X3) launch_h<16>(cv_b_h_kernel<4, 1, 16, true>, attr3, lds3, tiles_h(b, s, 4, 1), a);
   else if (small) launch_h<4>(cv_b_h_kernel<4, 1, 4>, attr_s, lds, tiles_h(b, s, 4, 1), a);
   else launch_h<16>(cv_b_h_kernel<4, 1, 16>, attr, lds, tiles_h(b, s, 4, 1), a);
   check_launch("cv_fused_b_h");

@@ -784,11 +784,12 @@ extern "C" void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int
 
 extern "C" void cv_fused_a1_kernel_wrapper(int b, int n, int s, int k, int c, const float *xyz1,
                                            const float *feat1, const float *xyz2, const float *feat2,
-                                           const int *idx, const float *packed_w, float *pix) {
+                                           const int *idx, const float *packed_w, float *pix, int pix_slots) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a1: nsample_q=%d outside [1,32]", k);
+  PWCLO_REQUIRE(cv_pix_slots_valid(k, pix_slots), "cv_fused_a1: pix_slots=%d invalid for nsample_q=%d", pix_slots, k);
   CVArgs a{xyz1, feat1, xyz2, feat2, idx, packed_w, pix, nullptr, b, n, s, k, fl_tuning("PWCLO_FL_STAGGER", 0)};
-  const int kp = cv_pix_slots(k);
+  const int kp = pix_slots;
 #define A1_CASE(C, KP)                                                                              \
   if (c == C && kp == KP) {                                                                         \
     static bool attr = false, attr1 = false;                                                        \
@@ -806,19 +807,27 @@ extern "C" void cv_fused_a1_kernel_wrapper(int b, int n, int s, int k, int c, co
 
 extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const float *xyz1,
                                            const float *xyz2, const int *idx, const float *packed_w,
-                                           const float *pix, float *out) {
+                                           const float *pix, float *out, int pix_slots, int wfmt,
+                                           int packed_floats) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "cv_fused_a2: nsample_q=%d outside [1,32]", k);
+  PWCLO_REQUIRE(cv_pix_slots_valid(k, pix_slots), "cv_fused_a2: pix_slots=%d invalid for nsample_q=%d", pix_slots, k);
   PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 32)), "cv_fused_a2: batch too large for 32-bit offsets (b=%d)", b);
   CVArgs a{xyz1, nullptr, xyz2, nullptr, idx, packed_w, const_cast<float *>(pix), out, b, n, s, k,
            fl_tuning("PWCLO_FL_STAGGER", 0)};
-  const int kp = cv_pix_slots(k);
+  const int kp = pix_slots;
   constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(8, 8) + layer_floats(8, 4));
+  {
+    constexpr int lds3c = 4 * (layer_floats(1, 4) + layer_floats_bf3(8, 8) + layer_floats_bf3(8, 4));
+    PWCLO_REQUIRE(wfmt == PWCLO_WFMT_F32 || kp == 6 || kp == 32,
+                  "cv_fused_a2: the split format exists for 6 / 32 pixel slots only (got %d)", kp);
+    PWCLO_REQUIRE_PACKED("cv_fused_a2", wfmt, packed_floats, lds / 4, lds3c / 4);
+  }
   static bool attr32 = false, attr16 = false, attr8 = false, attr16w = false, attr8w = false, attr6 = false;
   static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);
   static bool attr6s = false;
   const long long t6 = (long long)b * ((s + 7) / 8);
-  if (bf16x3_enabled() && (kp == 6 || kp == 32)) {     // experimental split path (mlp_core.hpp)
+  if (wfmt == PWCLO_WFMT_BF16X3) {     // opt-in split path (mlp_core.hpp)
     constexpr int lds3 = 4 * (layer_floats(1, 4) + layer_floats_bf3(8, 8) + layer_floats_bf3(8, 4));
     static bool b6 = false, b6s = false, b32 = false;
     if (kp == 6 && t6 <= 2048) launch_persistent<4>(cv_a2_dense6_kernel<4, true>, b6s, lds3, t6, a);

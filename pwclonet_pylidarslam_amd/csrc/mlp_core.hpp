@@ -236,12 +236,19 @@ constexpr int layer_floats_any(int nbi, int nbo) {
   return (BF3 && nbi % 2 == 0) ? layer_floats_bf3(nbi, nbo) : layer_floats(nbi, nbo);
 }
 
-// Read at every launch (not cached) so that one process can pack and run both formats: the packed
-// weights a wrapper receives must have been produced under the same setting (fused.py reads it too).
-static inline int bf16x3_enabled() {
-  const char *e = getenv("PWCLO_BF16X3");
-  return e ? atoi(e) : 0;
-}
+// The format of a packed weight buffer is a property of the BUFFER, fixed when it was packed (fused.py records it
+// on the packed object): the stack launchers take it as an explicit argument `wfmt` together with the buffer's
+// length in floats, and refuse a length that does not match the layout the selected kernel will index
+// (a buffer packed in one format and launched as the other would otherwise be read out of bounds, silently).
+enum : int { PWCLO_WFMT_F32 = 0, PWCLO_WFMT_BF16X3 = 1 };
+#define PWCLO_REQUIRE_PACKED(what, wfmt, packed_floats, floats_f32, floats_bf3)                                  \
+  do {                                                                                                           \
+    PWCLO_REQUIRE((wfmt) == PWCLO_WFMT_F32 || (wfmt) == PWCLO_WFMT_BF16X3, what ": unknown weight format %d",     \
+                  (int)(wfmt));                                                                                  \
+    const int expect_ = (wfmt) == PWCLO_WFMT_BF16X3 ? (int)(floats_bf3) : (int)(floats_f32);                       \
+    PWCLO_REQUIRE((packed_floats) == expect_, what ": packed weights hold %d floats, format %d needs %d",          \
+                  (int)(packed_floats), (int)(wfmt), expect_);                                                   \
+  } while (0)
 
 // Hoisting.  The first layer of a grouped MLP is linear in its concatenated input
 // [geometry(q,p) | feat_centre[s] | feat_nbr[n]], and the feature parts depend on ONE point, not on
@@ -305,14 +312,12 @@ __device__ __forceinline__ float group_max_nonneg(float v) {
 
 // ---- pixel bookkeeping --------------------------------------------------------------------------
 // Neighbour slots per query of the cost volume's per-pixel feature buffer (cv_a1 -> cv_a2): K
-// rounded up to 8 / 16 / 32, except K == 6 (the refinement levels), which is stored densely and
-// consumed by cv_a2_dense6_kernel.  PWCLO_DENSE6=0 restores the padded layout (A/B switch).
-// fused.py: cv_pix_slots mirrors this.
-static inline int cv_pix_slots(int k) {
-  static int dense6 = -1;
-  if (dense6 < 0) { const char *e = getenv("PWCLO_DENSE6"); dense6 = e ? atoi(e) : 1; }
-  if (k == 6 && dense6) return 6;
-  return k > 16 ? 32 : (k > 8 ? 16 : 8);
+// rounded up to 8 / 16 / 32, or 6 for K == 6 (the refinement levels: stored densely, consumed by the
+// dense-6 / in-lane kernels).  The CALLER chooses (it allocates the buffer: fused.py cv_pix_slots) and passes
+// the choice to both kernels as `pix_slots`; the launchers only validate it.
+static inline bool cv_pix_slots_valid(int k, int slots) {
+  if (slots == 6) return k == 6;
+  return (slots == 8 || slots == 16 || slots == 32) && k <= slots && (slots == 8 || k > slots / 2);
 }
 
 // Index of the wave inside its workgroup as a SCALAR: the compiler cannot know that threadIdx.x >> 6 is

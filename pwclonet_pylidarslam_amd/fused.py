@@ -49,24 +49,29 @@ def pack_layer(w, b, phys_map, nbo=None):
     return torch.cat((wp, bias)).contiguous()
 
 
-def bf16x3_enabled():
-    import os
-    return os.environ.get("PWCLO_BF16X3", "0") != "0"
+WFMT_F32, WFMT_BF16X3 = 0, 1     # include/pwclo_ops.h: packed-weight format of a stack (csrc/mlp_core.hpp)
 
 
-def _kname(name, split_capable=True):
+def default_wfmt():
+    """Format new packed objects are built in: fp32 operand tiles unless PWCLO_BF16X3=1 asks for the opt-in
+    three-term bf16 split.  Read ONCE per object, at pack time; the object records it
+    (``.wfmt``) and passes it with every launch, so a later change of the variable cannot make a kernel
+    index a buffer of the other layout."""
+    return WFMT_BF16X3 if os.environ.get("PWCLO_BF16X3", "0") != "0" else WFMT_F32
+
+
+def _kname(name, wfmt, split_capable=True):
     """Kernel name as rocprofv3 prints it: the stack kernels carry a trailing `bool BF3` template argument."""
-    return name[:-1] + (", true>" if split_capable and bf16x3_enabled() else ", false>")
+    return name[:-1] + (", true>" if split_capable and wfmt == WFMT_BF16X3 else ", false>")
 
 
-def _a2_kernel_name(kp, B, S):
-    import os
-    if kp == 6 and not bf16x3_enabled() and os.environ.get("PWCLO_LANE6", "1") != "0" and B * ((S + 15) // 16) > 1024:
+def _a2_kernel_name(kp, B, S, wfmt):
+    if kp == 6 and wfmt == WFMT_F32 and os.environ.get("PWCLO_LANE6", "1") != "0" and B * ((S + 15) // 16) > 1024:
         return "cv_a2_lane6_kernel<8>"
     if kp == 6:
-        return _kname("cv_a2_dense6_kernel<%d>" % (8 if B * ((S + 7) // 8) > 2048 else 4))
+        return _kname("cv_a2_dense6_kernel<%d>" % (8 if B * ((S + 7) // 8) > 2048 else 4), wfmt)
     return _kname({32: "cv_a2_kernel<32, 2, 8>", 16: "cv_a2_kernel<16, 1, 16>", 8: "cv_a2_kernel<8, 1, 16>"}[kp],
-                  split_capable=kp == 32)
+                  wfmt, split_capable=kp == 32)
 
 
 def pack_layer_bf3(w, b, phys_map, nbo=None):
@@ -109,16 +114,16 @@ def stack_macs(shared_mlp):
     return sum(int(l.conv.weight.shape[0]) * int(l.conv.weight.shape[1]) for l in shared_mlp)
 
 
-def pack_stack(shared_mlp, first_map, split=False):
+def pack_stack(shared_mlp, first_map, wfmt=WFMT_F32):
     """Pack every layer of a SharedMLP whose first layer reads the physical order `first_map`.
-    Returns (packed float tensor, [padded widths]).  ``split``: layers with an even number of input
-    blocks use the bf16x3 format when that path is enabled (kernels built on mlp_layer_any)."""
+    Returns (packed float tensor, [padded widths]).  ``wfmt`` = WFMT_BF16X3: layers with an even number of
+    input blocks use the bf16x3 format (kernels built on mlp_layer_any)."""
     parts, widths = [], []
     pm = first_map
     for layer in shared_mlp:
         w, b = fold_conv_bn(layer)
         nbo = (w.shape[0] + 15) // 16
-        parts.append((pack_layer_any if split else pack_layer)(w, b, pm, nbo))
+        parts.append(pack_layer_any(w, b, pm, nbo, wfmt))
         widths.append(16 * nbo)
         pm = chain_map(w.shape[0], nbo)
     return torch.cat(parts).contiguous(), widths
@@ -275,12 +280,14 @@ class FusedCostVolume:
         assert c1 == c2 and c1 in (16, 32, 64)
         self.c = c1
         self.nsample, self.nsample_q = module.nsample, module.nsample_q
+        self.kp = cv_pix_slots(module.nsample_q)               # per-pixel buffer layout, fixed at pack time
+        self.wfmt_a2 = default_wfmt() if self.kp in (6, 32) else WFMT_F32
         geo = list(range(10)) + [-1] * 6
         # mlp_convs input (costvolume.py:105-110): [geometry10, feat1 (C), feat2 gathered (C)]
         self.w_a1, w = pack_stack(module.mlp_convs, geo + [10 + c for c in range(2 * c1)])
         assert w == [128, 64, 64]
         wx1, wd = pack_stack(module.mlp_conv_xyz_1, geo)
-        w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)), split=cv_pix_slots(module.nsample_q) in (6, 32))     # [enc (64) | feat (64)], :133
+        w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)), self.wfmt_a2)     # [enc (64) | feat (64)], :133
         assert wd == [64] and wd2 == [128, 64]
         self.w_a2 = torch.cat((wx1, w2)).contiguous()
         wx2, _ = pack_stack(module.mlp_conv_xyz_2, geo)
@@ -300,19 +307,19 @@ class FusedCostVolume:
         kq, k = self.nsample_q, self.nsample
         if idx_q is None:
             idx_q = knn(kq, xyz2, xyz1)
-        kp = cv_pix_slots(kq)
+        kp = self.kp
         pix = torch.empty((B, S * kp, 64), dtype=torch.float32, device=dev)
         c = self.c
         _lib.annotate(family="mlp", flops=2.0 * B * S * kq * self.macs_a1,
                       bytes=4.0 * B * (S * kq * (1 + 3 + c + 64) + S * (3 + c)))
         _lib.call("cv_fused_a1_kernel_wrapper", dev, B, N, S, kq, self.c, _p(xyz1), _p(feat1), _p(xyz2),
-                  _p(feat2), _p(idx_q), _p(self.w_a1), _p(pix))
+                  _p(feat2), _p(idx_q), _p(self.w_a1), _p(pix), kp)
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel=_a2_kernel_name(kp, B, S),
+        _lib.annotate(family="mlp", kernel=_a2_kernel_name(kp, B, S, self.wfmt_a2),
                       flops=2.0 * B * S * kq * self.macs_a2,
                       bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
-                  _p(self.w_a2), _p(pix), _p(first))
+                  _p(self.w_a2), _p(pix), _p(first), kp, self.wfmt_a2, self.w_a2.numel())
         if idx is None:
             idx = knn(k, xyz1, xyz1)
         if taps is not None:
@@ -390,8 +397,8 @@ def run_linear_jobs(jobs):
 
 
 def cv_pix_slots(k):
-    """Neighbour slots per query of cv_a1's per-pixel buffer (csrc/mlp_core.hpp: cv_pix_slots)."""
-    import os
+    """Neighbour slots per query of cv_a1's per-pixel buffer: the caller's choice, passed to cv_a1 and cv_a2 as
+    `pix_slots` (csrc/mlp_core.hpp: cv_pix_slots_valid).  PWCLO_DENSE6=0 selects the padded layout for K = 6."""
     if k == 6 and os.environ.get("PWCLO_DENSE6", "1") != "0":
         return 6
     return 32 if k > 16 else (16 if k > 8 else 8)
@@ -412,21 +419,21 @@ def _zeros_like_bias(w):
     return torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
 
 
-def pack_layer_any(w, b, phys_map, nbo=None):
-    """``pack_layer_bf3`` when the bf16x3 path is on and the layer has an even number of 16-channel input
+def pack_layer_any(w, b, phys_map, nbo=None, wfmt=WFMT_F32):
+    """``pack_layer_bf3`` for the split format when the layer has an even number of 16-channel input
     blocks (csrc/mlp_core.hpp: mlp_layer_any / layer_floats_any), ``pack_layer`` otherwise."""
-    if bf16x3_enabled() and (len(phys_map) // 16) % 2 == 0:
+    if wfmt == WFMT_BF16X3 and (len(phys_map) // 16) % 2 == 0:
         return pack_layer_bf3(w, b, phys_map, nbo)
     return pack_layer(w, b, phys_map, nbo)
 
 
-def _pack_rest(layers, cout_prev):
+def _pack_rest(layers, cout_prev, wfmt):
     """Pack layers 2.. of a stack fed by a previous layer with `cout_prev` real outputs."""
     parts, widths = [], []
     for layer in layers:
         w, b = fold_conv_bn(layer)
         nbo = (w.shape[0] + 15) // 16
-        parts.append(pack_layer_any(w, b, chain_map(cout_prev, (cout_prev + 15) // 16), nbo))
+        parts.append(pack_layer_any(w, b, chain_map(cout_prev, (cout_prev + 15) // 16), nbo, wfmt))
         widths.append(16 * nbo)
         cout_prev = w.shape[0]
     return parts, widths
@@ -441,6 +448,7 @@ class FusedSAHoisted:
         cin = w1.shape[1]
         self.c_feat = cin - 3 if cin != 6 else 0
         nbo1 = (w1.shape[0] + 15) // 16
+        self.wfmt = default_wfmt()
         if self.c_feat:
             # original order [xyz_diff(3), feat(C)] (pointnet2_modules.py:222)
             self.pre_job = LinearJob(_pad_rows(w1[:, 3:], 16 * nbo1), _pad_rows(b1, 16 * nbo1))
@@ -448,7 +456,7 @@ class FusedSAHoisted:
         else:
             self.pre_job = None
             first = pack_layer(w1, b1, kstep_major_map(6), nbo1)
-        rest, widths = _pack_rest(layers[1:], w1.shape[0])
+        rest, widths = _pack_rest(layers[1:], w1.shape[0], self.wfmt)
         self.packed = torch.cat([first] + rest).contiguous()
         self.widths = [16 * nbo1] + widths
         self.c_out = layers[-1].conv.weight.shape[0]
@@ -465,7 +473,7 @@ class FusedSAHoisted:
         _lib.annotate(family="mlp", flops=2.0 * B * S * K * self.macs,
                       bytes=4.0 * B * (S * K * (1 + 3 + self.widths[0]) + 3 * S + S * self.c_out))
         _lib.call("sa_fused_h_kernel_wrapper", xyz.device, B, N, S, K, *self.widths, _p(xyz), _p(new_xyz),
-                  _p(pre), _p(idx), _p(self.packed), _p(out))
+                  _p(pre), _p(idx), _p(self.packed), _p(out), self.wfmt, self.packed.numel())
         return out
 
 
@@ -486,8 +494,9 @@ class FusedUpconvHoisted:
         w1, b1 = fold_conv_bn(layers[0])
         assert w1.shape == (128, 67), "set-upconv kernel is built for 64-channel coarse features"
         self.pre_job = LinearJob(w1[:, :64], b1)                     # original order [feat(64), diff(3)], :490
+        self.wfmt = default_wfmt()
         first = pack_layer(w1[:, 64:67], _zeros_like_bias(w1), kstep_major_map(3), 8)
-        rest, widths = _pack_rest(layers[1:], 128)
+        rest, widths = _pack_rest(layers[1:], 128, self.wfmt)
         assert widths == [64]
         self.packed = torch.cat([first] + rest).contiguous()
         c2 = list(module.post_mlp)[0].conv.weight.shape[1] - 64
@@ -501,11 +510,12 @@ class FusedUpconvHoisted:
         B, S, _ = xyz2.shape
         N, K = xyz1.shape[1], idx.shape[2]
         pooled = torch.empty((B, S, 64), dtype=torch.float32, device=xyz2.device)
-        lane = (not bf16x3_enabled() and os.environ.get("PWCLO_LANE_UP", "1") != "0" and B * ((S + 15) // 16) > 2048)
-        _lib.annotate(family="mlp", kernel="upconv_lane_kernel<16>" if lane else _kname("upconv_h_kernel<8, 1, 16>"), flops=2.0 * B * S * K * (self.macs - 64 * 128),
+        lane = (self.wfmt == WFMT_F32 and os.environ.get("PWCLO_LANE_UP", "1") != "0" and B * ((S + 15) // 16) > 2048)
+        _lib.annotate(family="mlp", kernel="upconv_lane_kernel<16>" if lane else _kname("upconv_h_kernel<8, 1, 16>", self.wfmt),
+                      flops=2.0 * B * S * K * (self.macs - 64 * 128),
                       bytes=4.0 * B * (S * K * (1 + 3 + 128) + 3 * S + 64 * S))
         _lib.call("upconv_fused_h_kernel_wrapper", xyz2.device, B, N, S, K, _p(xyz2), _p(xyz1), _p(pre),
-                  _p(idx), _p(self.packed), _p(pooled))
+                  _p(idx), _p(self.packed), _p(pooled), self.wfmt, self.packed.numel())
         return self.post(pooled, feat2)
 
 
@@ -517,17 +527,20 @@ class FusedCostVolumeHoisted:
         assert c1 == c2 and c1 in (16, 32, 64)
         self.c = c = c1
         self.nsample, self.nsample_q = module.nsample, module.nsample_q
+        self.kp = cv_pix_slots(module.nsample_q)               # per-pixel buffer layout, fixed at pack time
+        self.wfmt = default_wfmt()
+        self.wfmt_a2 = self.wfmt if self.kp in (6, 32) else WFMT_F32
         geo = list(range(10)) + [-1] * 6
         la = list(module.mlp_convs)
         w1, b1 = fold_conv_bn(la[0])                                   # [geo(10) | feat1 (C) | feat2 (C)]
         self.job_u = LinearJob(w1[:, 10:10 + c], b1)
         self.job_v = LinearJob(w1[:, 10 + c:10 + 2 * c], _zeros_like_bias(w1))
         first = pack_layer(w1[:, :10], _zeros_like_bias(w1), kstep_major_map(10), 8)
-        rest, widths = _pack_rest(la[1:], 128)
+        rest, widths = _pack_rest(la[1:], 128, self.wfmt)
         assert widths == [64, 64]
         self.w_a1 = torch.cat([first] + rest).contiguous()
         wx1, wd = pack_stack(module.mlp_conv_xyz_1, geo)
-        w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)), split=cv_pix_slots(module.nsample_q) in (6, 32))
+        w2, wd2 = pack_stack(module.mlp2_convs, list(range(128)), self.wfmt_a2)
         assert wd == [64] and wd2 == [128, 64]
         self.w_a2 = torch.cat((wx1, w2)).contiguous()
         wx2, _ = pack_stack(module.mlp_conv_xyz_2, kstep_major_map(10))
@@ -535,8 +548,8 @@ class FusedCostVolumeHoisted:
         w3, b3 = fold_conv_bn(lb[0])                                   # [enc2 (64) | feat1 (C) | first (64)]
         self.job_u2 = LinearJob(w3[:, 64:64 + c], b3)
         self.job_v2 = LinearJob(w3[:, 64 + c:], _zeros_like_bias(w3))
-        first_b = pack_layer_any(w3[:, :64], _zeros_like_bias(w3), list(range(64)), 8)
-        rest_b, wdb = _pack_rest(lb[1:], 128)
+        first_b = pack_layer_any(w3[:, :64], _zeros_like_bias(w3), list(range(64)), 8, self.wfmt)
+        rest_b, wdb = _pack_rest(lb[1:], 128, self.wfmt)
         assert wdb == [64]
         self.w_b = torch.cat([wx2, first_b] + rest_b).contiguous()
         self.macs_a1 = stack_macs(module.mlp_convs)
@@ -554,30 +567,30 @@ class FusedCostVolumeHoisted:
         kq, k, c = self.nsample_q, self.nsample, self.c
         if idx_q is None:
             idx_q = knn(kq, xyz2, xyz1)
-        kp = cv_pix_slots(kq)
+        kp = self.kp
         pix = torch.empty((B, S * kp, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel=_kname("cv_a1_h_kernel<%d, 1, 16>" % kp),
+        _lib.annotate(family="mlp", kernel=_kname("cv_a1_h_kernel<%d, 1, 16>" % kp, self.wfmt),
                       flops=2.0 * B * S * kq * (self.macs_a1 - 2 * c * 128),
                       bytes=4.0 * B * (S * kq * (1 + 3 + 128 + 64) + S * (3 + 128)))
         _lib.call("cv_fused_a1_h_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(u), _p(xyz2), _p(v), _p(idx_q),
-                  _p(self.w_a1), _p(pix))
+                  _p(self.w_a1), _p(pix), kp, self.wfmt, self.w_a1.numel())
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel=_a2_kernel_name(kp, B, S),
+        _lib.annotate(family="mlp", kernel=_a2_kernel_name(kp, B, S, self.wfmt_a2),
                       flops=2.0 * B * S * kq * self.macs_a2,
                       bytes=4.0 * B * (S * kq * (1 + 3 + 64) + S * (3 + 64)))
         _lib.call("cv_fused_a2_kernel_wrapper", dev, B, N, S, kq, _p(xyz1), _p(xyz2), _p(idx_q),
-                  _p(self.w_a2), _p(pix), _p(first))
+                  _p(self.w_a2), _p(pix), _p(first), kp, self.wfmt_a2, self.w_a2.numel())
         if idx is None:
             idx = knn(k, xyz1, xyz1)
         if taps is not None:
             taps[tap + ".idx_q"], taps[tap + ".idx"] = idx_q, idx
         (v2,) = run_linear_jobs([(self.job_v2, first)])
         out = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel=_kname("cv_b_h_kernel<4, 1, %d>" % (4 if B * ((S * 4 + 15) // 16) <= 2048 else 16)),
+        _lib.annotate(family="mlp", kernel=_kname("cv_b_h_kernel<4, 1, %d>" % (4 if B * ((S * 4 + 15) // 16) <= 2048 else 16), self.wfmt),
                       flops=2.0 * B * S * k * (self.macs_b - (c + 64) * 128),
                       bytes=4.0 * B * (S * k * (1 + 3 + 128 + 64) + S * (3 + 128 + 64)))
         _lib.call("cv_fused_b_h_kernel_wrapper", dev, B, S, k, _p(xyz1), _p(u2), _p(v2), _p(first), _p(idx),
-                  _p(self.w_b), _p(out))
+                  _p(self.w_b), _p(out), self.wfmt, self.w_b.numel())
         return out
 
 

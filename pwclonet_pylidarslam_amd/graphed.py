@@ -58,8 +58,18 @@ class GraphedForward:
         s1.copy_(xyz_f1)
         s2.copy_(xyz_f2)
         graph.replay()
-        self.last_log_dict = log
+        self.last_log_dict = self._replay_log(log, xyz_f1.device)
         return pose
+
+    def _replay_log(self, log, device):
+        """log_dict of THIS replay: a fresh lazy view of the graph's static buffers (nothing cached from an
+        earlier batch) that waits for the replay before its first read and honours the net's log_mode
+        (``host`` -> host tensors, like the reference's log_dict)."""
+        if not hasattr(log, "fresh"):
+            return log
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        return log.fresh(to_host=self.net.log_mode == "host", ready=ev.synchronize)
 
 
 class PipelinedForward:
@@ -189,7 +199,9 @@ class StagedPipeline:
             sl["g_r"].replay()
             sl["ev_r"] = torch.cuda.Event()
             sl["ev_r"].record(sr)
-        self.last_log_dict = sl["log"]
+        log = sl["log"]
+        self.last_log_dict = (log.fresh(to_host=self.net.log_mode == "host", ready=sl["ev_r"].synchronize)
+                              if hasattr(log, "fresh") else log)
         return sl["pose"], k
 
     def prepare(self, xyz_f1, xyz_f2):

@@ -33,16 +33,30 @@ class LazyLogDict(dict):
     """``log_dict`` whose values are computed on first access.  The reference builds
     ``embedding_mask`` / ``point_cloud`` inside forward (pwclo_net.py:186-193, with a D2H sync);
     here the forward only keeps references and the softmax / norm / copies run when (and if)
-    a logger reads them."""
+    a logger reads them.  ``ready``: optional callable run once before the first read (graph replay:
+    waits for the replay that filled the source buffers).  Every way of reading a dict goes through
+    the computed values (``[]``, ``get``, ``items``, ``values``)."""
 
-    def __init__(self, mask_pm, cloud_pm, to_host):
+    KEYS = ("embedding_mask", "point_cloud")
+
+    def __init__(self, mask_pm, cloud_pm, to_host, ready=None):
         super().__init__()
         self._src = (mask_pm, cloud_pm, to_host)
-        dict.__setitem__(self, "embedding_mask", None)
-        dict.__setitem__(self, "point_cloud", None)
+        self._ready = ready
+        for k in self.KEYS:
+            dict.__setitem__(self, k, None)
+
+    def fresh(self, to_host=None, ready=None):
+        """A new, un-cached view of the same source buffers (one per graph replay: the buffers are static,
+        their contents are the latest batch's)."""
+        m1, pc, th = self._src
+        return LazyLogDict(m1, pc, th if to_host is None else to_host, ready)
 
     def __getitem__(self, key):
-        if dict.__getitem__(self, key) is None:
+        if key in self.KEYS and dict.__getitem__(self, key) is None:
+            if self._ready is not None:
+                self._ready()
+                self._ready = None
             m1, pc, to_host = self._src
             if to_host:
                 m1, pc = m1.cpu(), pc.cpu()
@@ -52,6 +66,15 @@ class LazyLogDict(dict):
                 val = pc
             dict.__setitem__(self, key, val)
         return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
 
 
 def _unit(q):
@@ -102,11 +125,24 @@ class PWCLONet(nn.Module):
 
     # ---- fused eval-mode path ---------------------------------------------------------------------
     def prepare_fused(self):
-        """Fold BatchNorm and pack the weights for the fused kernels (eval mode only)."""
+        """Fold BatchNorm and pack the weights for the fused kernels (eval mode only).  The packed copy is tied
+        to the parameters it was made from: ``train()``, ``load_state_dict()``, ``.to()`` / ``.cuda()`` /
+        ``.float()`` (anything that goes through ``_apply``) drop it, and an in-place edit of any parameter or
+        buffer (optimizer step, ``copy_``) is noticed through the tensors' version counters at the next eager
+        forward, which re-packs."""
         from ..fused import FusedPWCLONet
         self.eval()
         self._fused = FusedPWCLONet(self)
+        self._fused_tensors = list(self.parameters()) + list(self.buffers())
+        self._fused_versions = self._state_versions()
         return self
+
+    def _state_versions(self):
+        return tuple(t._version for t in self._fused_tensors)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._fused = None          # packed weights live on the old device / dtype
+        return super()._apply(fn, *args, **kwargs)
 
     def _fused_log_dict(self, inter):
         """The reference's log_dict (pwclo_net.py:186-193) from the fused path's point-major tensors."""
@@ -133,6 +169,8 @@ class PWCLONet(nn.Module):
 
     def forward(self, xyz_f1, points_f1, xyz_f2, points_f2, bn_decay=None):
         if self._fused is not None and not self.training and points_f1 is None and points_f2 is None:
+            if not torch.cuda.is_current_stream_capturing() and self._state_versions() != self._fused_versions:
+                self.prepare_fused()            # a parameter / buffer was edited in place since packing
             pose, inter = self._fused(xyz_f1, xyz_f2, return_intermediates=True)
             return pose, self._fused_log_dict(inter)
         cf = lambda z: z.permute(0, 2, 1).contiguous()

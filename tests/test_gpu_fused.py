@@ -375,3 +375,69 @@ def test_bf16x3_split_path_matches_golden(cuda, case, monkeypatch):
     close(pm(inter["flow"]), torch.from_numpy(z["cv3.out"]))
     assert (pose - pose32).abs().max().item() < 2e-6
     assert not torch.equal(inter["flow"], inter32["flow"])                        # it really is the other arithmetic
+
+
+def test_weight_format_travels_with_the_packed_object(cuda, monkeypatch):
+    """the packed-weight format used to be re-read from the environment at every launch.  Now it is
+    recorded on the packed object and passed to the launcher together with the buffer length: an object packed in
+    the split format keeps running the split kernels after the variable changes, and a format / length mismatch is
+    refused by the launcher (PWCLO_EINVAL -> RuntimeError) instead of indexing the wrong layout."""
+    name = "pose_warp_refinement_2.setupconv_features"
+    mod, osd = filled(PointnetFPModulePWCLONet(nsample=8, mlp=[64, 128, 64], post_mlp=[64 + 32, 64],
+                                               radius=0.2, knn=True, use_xyz=True, bn=True), name)
+    xyz2, xyz1 = cloud(3, 2, 512), cloud(4, 2, 128)
+    g = torch.Generator().manual_seed(5)
+    f2, f1 = torch.randn(2, 32, 512, generator=g), torch.randn(2, 64, 128, generator=g)
+    ref = M.set_upconv(osd, name, 8, xyz2, xyz1, f2, f1)
+    idx = O.knn_point_with_dist(8, xyz1, xyz2)[1]
+    monkeypatch.setenv("PWCLO_BF16X3", "1")
+    up3 = fused.FusedUpconvHoisted(mod.to(cuda))                   # packed in the split format
+    monkeypatch.setenv("PWCLO_BF16X3", "0")
+    up0 = fused.FusedUpconvHoisted(mod.to(cuda))                   # packed as fp32 tiles
+    assert (up3.wfmt, up0.wfmt) == (fused.WFMT_BF16X3, fused.WFMT_F32) and up3.packed.numel() != up0.packed.numel()
+    args = lambda up: (xyz2.to(cuda), xyz1.to(cuda), pm(f2).to(cuda),
+                       fused.run_linear_jobs(up.jobs(pm(f1).to(cuda)))[0], idx.to(cuda))
+    out3, out0 = up3(*args(up3)), up0(*args(up0))                  # each runs ITS format, whatever the env says now
+    close(pm(out3), ref)
+    close(pm(out0), ref)
+    assert not torch.equal(out3, out0)
+    up0.wfmt = fused.WFMT_BF16X3                                   # lie about the format: refused, not mis-indexed
+    with pytest.raises(RuntimeError, match="packed weights hold"):
+        up0(*args(up0))
+
+
+def test_log_dict_under_graph_replay_is_per_batch(cuda):
+    """GraphedForward handed the capture-time LazyLogDict back on every replay, so every later batch read
+    the first batch's cached values.  Each replay now gets a fresh lazy view of the static buffers that waits for
+    the replay before reading."""
+    from pwclonet_pylidarslam_amd.graphed import GraphedForward
+    pc1, pc2, _, _ = synthetic.kitti_like_pair(45, 2048, 2)
+    x1 = torch.from_numpy(pc1[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    x2 = torch.from_numpy(pc2[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    net = _net(cuda)
+    net.log_mode = "host"
+    net.prepare_fused()
+    with torch.no_grad():
+        _, log_a = net(x1, None, x2, None)
+        _, log_b = net(x2, None, x1, None)
+    want_a, want_b = log_a["embedding_mask"].clone(), log_b["embedding_mask"].clone()
+    assert not torch.equal(want_a, want_b)
+    gf = GraphedForward(net)
+    gf(x1, x2)
+    la = gf.last_log_dict
+    assert torch.equal(la["embedding_mask"], want_a) and la["embedding_mask"].device.type == "cpu"
+    gf(x2, x1)
+    lb = gf.last_log_dict
+    assert torch.equal(lb["embedding_mask"], want_b)                 # the second batch's values, not the first's
+    assert torch.equal(dict(lb.items())["point_cloud"], log_b["point_cloud"])
+    assert all(v is not None for v in lb.values()) and lb.get("embedding_mask") is not None
+    # .to() after packing drops the packed weights (they would point at the old device); an in-place edit re-packs
+    assert net._fused is not None
+    net.to(cuda)
+    assert net._fused is None
+    net.prepare_fused()
+    before = net(x1, None, x2, None)[0].clone()
+    with torch.no_grad():
+        net.pose_calculator_4.conv1d_t.conv.bias.add_(0.25)
+    after = net(x1, None, x2, None)[0]
+    assert (after[:, 3, :3] - before[:, 3, :3]).abs().min().item() > 0.2      # level-4 translation moved by the edit

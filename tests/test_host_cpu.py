@@ -239,3 +239,116 @@ def test_pointnet2_ops_package_name_and_setup():
     out = subprocess.run([sys.executable, "setup.py", "--name", "--version"], cwd=root, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert out.stdout.split()[-2:] == ["pointnet2_ops", pointnet2_ops.__version__]
+
+
+# ---- multi-GPU launch path and the data-parallel training unit ---------------------
+
+def test_bench_spawns_its_own_ranks_when_not_under_torchrun():
+    """`python bench.py --gpus 2` with no torchrun around it: the parent starts two rank processes (before any
+    GPU call), they rendezvous on 127.0.0.1, fence, MAX-reduce the timed region, and rank 0 prints ONE line.
+    --dry-run replaces the GPU step by a host sleep over gloo, so the plumbing runs in the CPU container."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    row = json.loads(lines[0])
+    assert row["dry_run"] is True and row["n_gpus"] == 2 and row["steps"] == 3
+    assert row["global_pairs"] == 2 * 32 * 3            # both ranks' shards were summed
+    assert row["ms_per_step"] >= 2.0                    # the slower rank (2 ms sleeps) defines the step time
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """Without enough devices the supervising process stops with a clear message before spawning anything."""
+    import torch
+    n = torch.cuda.device_count() + 1 if torch.cuda.device_count() else 2
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 2 and "GPU(s) visible" in out.stderr, (out.returncode, out.stderr)
+
+
+DDP_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch
+import torch.nn as nn
+from pwclonet_pylidarslam_amd import dist_util
+from pwclonet_pylidarslam_amd.loss import PWCLONetLossModule
+from pwclonet_pylidarslam_amd.training import PWCLONetWithLoss, ddp_wrap, gradient_bucket_values
+
+class StandIn(nn.Module):            # a CPU stand-in with the network's call signature (the product has no CPU path)
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(6, 28)
+    def forward(self, x1, p1, x2, p2):
+        return self.lin(torch.cat((x1.mean(2), x2.mean(2)), 1)).reshape(-1, 4, 7), {}
+
+rank, world = dist_util.init("gloo")
+torch.manual_seed(0)                 # same initial weights on both ranks
+unit = PWCLONetWithLoss(StandIn(), PWCLONetLossModule(dict(with_exp_weights=True, init_weights=[0.0, -2.5],
+                                                          loss_option="l2_norm", nb_levels=4, scalar_last=False)))
+ddp = ddp_wrap(unit)
+g = torch.Generator().manual_seed(100 + rank)          # different data per rank
+x1, x2 = torch.randn(4, 3, 50, generator=g), torch.randn(4, 3, 50, generator=g)
+gt = torch.randn(4, 7, generator=g)
+loss, pose, log = ddp(x1, x2, gt)
+loss.backward()
+s_ddp = unit.loss_module.exp_weighting.s_param.grad.clone()
+w_ddp = unit.pwclonet.lin.weight.grad.clone()
+# the same step without DDP, local data only
+unit.zero_grad()
+loss2, _, _ = unit(x1, x2, gt)
+loss2.backward()
+s_loc = unit.loss_module.exp_weighting.s_param.grad.clone()
+both = [torch.zeros_like(s_loc) for _ in range(world)]
+torch.distributed.all_gather(both, s_loc)
+want = sum(both) / world
+print("RESULT", rank, gradient_bucket_values(unit), s_ddp.tolist(), want.tolist(), s_loc.tolist(),
+      float(w_ddp.abs().sum()), flush=True)
+dist_util.finish()
+"""
+
+
+def test_ddp_unit_reduces_network_and_loss_weights(tmp_path):
+    """2 ranks, gloo: under ``ddp_wrap(PWCLONetWithLoss(net, loss))`` the loss module's learnable ``s_param`` takes
+    part in the gradient all-reduce (its gradient equals the mean of the ranks' local gradients and is identical
+    on both ranks), which the round-1 step -- DDP around the network alone -- did not do."""
+    import ast
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER % ROOT)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    rows = [l for o in outs for l in o.splitlines() if l.startswith("RESULT")]
+    assert len(rows) == 2, outs
+    import re
+    vals = []
+    for r in rows:
+        lists = [ast.literal_eval(m) for m in re.findall(r"\[[^\]]*\]", r)]
+        head = r.split()
+        vals.append((int(head[1]), int(head[2]), lists[0], lists[1], lists[2]))
+    vals.sort()
+    (_, n0, s0, want0, loc0), (_, n1, s1, want1, loc1) = vals
+    assert n0 == n1 == 6 * 28 + 28 + 2                    # the stand-in's parameters + the two loss weights
+    assert s0 == s1                                       # replicas agree after the all-reduce
+    assert all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(s0, want0))
+    assert loc0 != loc1                                   # ... although their local gradients differ
+
+
+def test_training_unit_parameter_count():
+    """the gradient message is 775 068 + 2 fp32 values."""
+    from pwclonet_pylidarslam_amd.loss import PWCLONetLossModule
+    from pwclonet_pylidarslam_amd.pwclonet import PWCLONet
+    from pwclonet_pylidarslam_amd.training import PWCLONetWithLoss, gradient_bucket_values
+    net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device="cpu", scalar_last=False))
+    unit = PWCLONetWithLoss(net, PWCLONetLossModule(dict(with_exp_weights=True, init_weights=[0.0, -2.5],
+                                                         loss_option="l2_norm", nb_levels=4, scalar_last=False)))
+    assert gradient_bucket_values(unit) == 775068 + 2
+    assert sorted(k for k in unit.state_dict() if "s_param" in k) == ["loss_module.exp_weighting.s_param"]

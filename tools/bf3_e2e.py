@@ -6,6 +6,7 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import pwclonet_pylidarslam_amd  # noqa: F401
+pwclonet_pylidarslam_amd.configure_hw_queues(8)
 import torch
 
 from oracle import model as omodel

@@ -7,7 +7,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import pwclonet_pylidarslam_amd  # noqa: F401  (sets GPU_MAX_HW_QUEUES before the runtime starts)
+import pwclonet_pylidarslam_amd  # noqa: F401
+pwclonet_pylidarslam_amd.configure_hw_queues(8)
 import torch
 
 from pwclonet_pylidarslam_amd import preprocess

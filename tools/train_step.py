@@ -15,12 +15,14 @@ import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pwclonet_pylidarslam_amd  # noqa: E402,F401
+pwclonet_pylidarslam_amd.configure_hw_queues(8)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
 from pwclonet_pylidarslam_amd import dist_util  # noqa: E402
 from pwclonet_pylidarslam_amd.loss import PWCLONetLossModule  # noqa: E402
 from pwclonet_pylidarslam_amd.pwclonet import PWCLONet  # noqa: E402
+from pwclonet_pylidarslam_amd.training import PWCLONetWithLoss, ddp_wrap, gradient_bucket_values  # noqa: E402
 
 
 def main():
@@ -34,8 +36,10 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture forward + loss + backward + Adam into one hipGraph (single GPU only)")
     a = ap.parse_args()
+    if a.gpus > 1 and not dist_util.launched_by_torchrun():      # supervise N fresh ranks; no GPU call made here
+        sys.exit(dist_util.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
     rank, local_rank, world = dist_util.env_world()
-    assert world == a.gpus
+    assert world == a.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist_util.init("nccl", dev)
@@ -44,11 +48,11 @@ def main():
                         log_mode="none")).to(dev).train()
     loss_mod = PWCLONetLossModule(dict(with_exp_weights=True, init_weights=[0.0, -2.5], loss_option="l2_norm",
                                        nb_levels=4, scalar_last=False)).to(dev)
-    model = net
-    if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], broadcast_buffers=False)
-    opt = torch.optim.Adam(list(net.parameters()) + list(loss_mod.parameters()), lr=1e-4,
-                           capturable=a.graph, fused=True if a.fused_adam else None)
+    # network + loss in ONE module: the all-reduce carries the 775 068 network gradients and the loss module's two
+    # learnable weights -- with the network alone under DDP the replicas' loss weights drift
+    unit = PWCLONetWithLoss(net, loss_mod)
+    model = ddp_wrap(unit, dev) if world > 1 else unit
+    opt = torch.optim.Adam(unit.parameters(), lr=1e-4, capturable=a.graph, fused=True if a.fused_adam else None)
     x1, x2 = bench.make_batch(a.batch, a.npoints, 2000 + rank, dev)
     g = torch.Generator().manual_seed(3 + rank)
     gt = torch.randn(a.batch, 7, generator=g) * 0.1
@@ -57,8 +61,7 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        pose, _ = model(x1, None, x2, None)
-        loss, _ = loss_mod(pose, gt)
+        loss, _pose, _log = model(x1, x2, gt)
         loss.backward()
         opt.step()
         return loss
@@ -75,8 +78,7 @@ def main():
         graph = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(graph):
-            pose, _ = model(x1, None, x2, None)
-            static_loss, _ = loss_mod(pose, gt)
+            static_loss, _pose, _log = model(x1, x2, gt)
             static_loss.backward()
             opt.step()
         eager_step = step
@@ -98,7 +100,8 @@ def main():
                           "value": world * a.batch * a.steps / dt, "unit": "frame-pairs/s", "n_gpus": world,
                           "ms_per_step": 1e3 * dt / a.steps, "batch_per_gpu": a.batch, "dtype": "f32",
                           "launch": "one hipGraph per step" if a.graph else "eager (module graph, torch autograd)", "loss_first_last": [losses[0], losses[-1]],
-                          "collective": "DDP all-reduce of 775k fp32 grads" if world > 1 else "none"}), flush=True)
+                          "collective": ("DDP all-reduce of %d fp32 gradient values (network + loss weights), one bucket"
+                                         % gradient_bucket_values(unit)) if world > 1 else "none"}), flush=True)
     dist_util.finish()
 
 
