@@ -192,13 +192,18 @@ def roofline_objects(fam):
     return roof, kernels
 
 
-def cpu_baseline(net, npoints, timed=5):
+def cpu_baseline(net, npoints, timed=5, threads=0):
     """the CPU oracle (restatement of the reference path, pinned bit-identically to the
     imported reference in the build container) on the same KITTI-shaped pairs, batch 1 and batch 4, eval mode,
     fp32, 1 warm-up + `timed` (>= 3) forwards each, MEDIAN reported.  All host cores are used: torch's CPU
     convolutions with its default intra-op threads, the C ops' FPS (over clouds) and knn (over queries) loops
     with OpenMP.  `value` is the better of the two batch sizes.  A baseline, not a target."""
     from oracle import model as omodel, ops as oops
+    cores = oops.usable_host_cores()                 # cgroup quota, not the host's 256 hardware threads
+    if threads:
+        cores = threads
+    torch.set_num_threads(cores)
+    oops.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     x1, x2 = make_batch(4, npoints, 999, torch.device("cpu"))
     rows, t_all = {}, time.perf_counter()
@@ -213,8 +218,9 @@ def cpu_baseline(net, npoints, timed=5):
         rows["batch%d" % bsz] = {"median_s_per_forward": ts[len(ts) // 2], "min_s": ts[0], "max_s": ts[-1],
                                  "pairs_per_s": bsz / ts[len(ts) // 2], "timed_forwards": len(ts)}
     best = max(rows.values(), key=lambda r: r["pairs_per_s"])
-    return {"value": best["pairs_per_s"], "unit": "frame-pairs/s", "cores": os.cpu_count(), "kind": "port",
-            "torch_threads": torch.get_num_threads(), "c_ops_threads": oops.num_threads(), **rows,
+    return {"value": best["pairs_per_s"], "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            "os_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(),
+            "c_ops_threads": oops.num_threads(), **rows,
             "sample": "oracle.model on 2x%d-pt pairs: batch 1 and batch 4, 1 warm-up + %d timed forwards each, median; "
                       "os.cpu_count() = %d, torch.get_num_threads() = %d, C ops (FPS over clouds, knn over queries) on "
                       "%d OpenMP threads; %.1f s of CPU work in total"
@@ -313,6 +319,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=5, help="timed CPU forwards per batch size (>= 3)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads of the CPU baseline (0 = the cgroup CPU quota / affinity of this process)")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra (untimed-region) measurement of the opt-in bf16x3 split path")
     ap.add_argument("--dry-run", action="store_true",
@@ -422,7 +430,7 @@ def main():
                 and args.pipeline == "whole" and os.environ.get("PWCLO_BF16X3", "0") == "0":
             out["variants"] = {"bf16x3": bf16x3_variant(args, dev, x1, x2, pose.clone(), pipe.streams)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(net, args.npoints, args.cpu_forwards)
+            out["cpu_baseline"] = cpu_baseline(net, args.npoints, args.cpu_forwards, args.cpu_threads)
         print(json.dumps(out), flush=True)
     dist_util.finish()
 

@@ -310,6 +310,29 @@ void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xyz1, const f
                                  const float *v2, const float *first, const int *idx,
                                  const float *packed_w, float *out, int wfmt, int packed_floats);
 
+/* ---- 5. KITTI odometry evaluation of predicted poses ---------------------------
+ * Replaces the per-sample host loops of /root/reference/train.py:866-893 (pose row -> 4x4 via quat2mat :762-795),
+ * slam/common/kitti360_utils.py:406-431 (relative -> absolute poses), evaluation.py:198-215 (trajectory distances)
+ * and evaluation.py:236-271 = slam/eval/eval_odometry.py:316-361 (segment errors).  All matrices are 4x4 row-major
+ * fp64 in device memory; frames of all sequences are stored back to back, sequence s owning frames
+ * [seq_start[s], seq_start[s+1]) (seq_start: nseq+1 ints in DEVICE memory). */
+
+/* rows: n pose rows [tx ty tz qw qx qy qz] fp32, row_stride floats apart (28 for level 1 of a (B,4,7) pose_params
+ * tensor) -> T (n,4,4) = [[R(q) t],[0 0 0 1]], or its inverse when invert != 0 (the reference stores the inverse
+ * as the "relative pose", train.py:878). */
+void odom_rows_to_transforms_kernel_wrapper(int n, int row_stride, const float *rows, double *T, int invert);
+/* abs[f] = T[first] . ... . T[f] inside every sequence (kitti360_utils.py:422-426 applied to rel = T^-1). */
+void odom_accumulate_kernel_wrapper(int nseq, const int *seq_start, const double *T, double *abs_out);
+/* dist[f] = sum_{i<=f} |p[i] - p[i-1]| (dist[first] = 0) from the translations of `poses`. */
+void odom_cumulative_distance_kernel_wrapper(int nseq, const int *seq_start, const double *poses, double *dist);
+/* One slot per (sequence, first frame in 0,step,2*step.., segment length): slot_start (nseq+1 ints, DEVICE) with
+ * slot_start[s+1]-slot_start[s] = ceil(n_s/step)*nlen, total_slots = slot_start[nseq].  err (total_slots,5) =
+ * [first_frame, r_err/len, t_err/len, len, speed] as evaluation.py:270; valid[slot] = 0 where the sequence is too
+ * short for that segment (the reference skips those).  lengths: nlen doubles in DEVICE memory. */
+void odom_sequence_errors_kernel_wrapper(int nseq, int total_slots, const int *seq_start, const int *slot_start,
+                                         const double *poses_gt, const double *poses_result, const double *dist,
+                                         int step, int nlen, const double *lengths, double *err, int *valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,8 @@ def lib():
         L.oracle_knn_point.argtypes = [_i, _i, _i, _i, _F, _F, _I, _F]
         L.oracle_num_threads.argtypes = []
         L.oracle_num_threads.restype = _i
+        L.oracle_set_num_threads.argtypes = [_i]
+        L.oracle_set_num_threads.restype = None
         _lib = L
     return _lib
 
@@ -68,6 +70,32 @@ def _n(t):
 def num_threads():
     """Host threads the C oracle's FPS (over clouds) and knn (over queries) loops use."""
     return lib().oracle_num_threads()
+
+
+def set_num_threads(n):
+    lib().oracle_set_num_threads(int(n))
+
+
+def usable_host_cores():
+    """Cores this process may actually use: the cgroup CPU quota when there is one (a container on a 256-thread host
+    is typically given a share; 128 OpenMP threads on a 16-core quota run SLOWER than 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def opt_n_threads(work_size):

@@ -325,6 +325,8 @@ void oracle_knn_point(int b, int n, int s, int nsample, const float *xyz,
 #ifdef _OPENMP
 #include <omp.h>
 int oracle_num_threads(void) { return omp_get_max_threads(); }
+void oracle_set_num_threads(int n) { if (n >= 1) omp_set_num_threads(n); }
 #else
 int oracle_num_threads(void) { return 1; }
+void oracle_set_num_threads(int n) { (void)n; }
 #endif

@@ -63,6 +63,10 @@ SIGNATURES = {
     "upconv_fused_h_kernel_wrapper": ([_i] * 4 + [_F] * 6 + [_i] * 2, None),
     "cv_fused_a1_h_kernel_wrapper": ([_i] * 4 + [_F] * 7 + [_i] * 3, None),
     "cv_fused_b_h_kernel_wrapper": ([_i] * 3 + [_F] * 7 + [_i] * 2, None),
+    "odom_rows_to_transforms_kernel_wrapper": ([_i, _i, _F, _F, _i], None),
+    "odom_accumulate_kernel_wrapper": ([_i, _F, _F, _F], None),
+    "odom_cumulative_distance_kernel_wrapper": ([_i, _F, _F, _F], None),
+    "odom_sequence_errors_kernel_wrapper": ([_i, _i] + [_F] * 5 + [_i, _i] + [_F] * 3, None),
 }
 
 _lib = None

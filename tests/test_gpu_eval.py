@@ -1,0 +1,118 @@
+"""GPU parity of the on-device odometry evaluation against values recorded from the imported
+reference (tests/golden/eval_cases.npz, oracle/gen_eval_golden.py) and against the NumPy oracle.
+
+fp64 throughout; the kernels compose SE(3) transforms with a wave-level scan (a different association of the same
+products than the reference's sequential loop) and invert [R t] in closed form, so the bound is rounding-level:
+1e-9 absolute on poses (trajectories of ~1 km), 1e-7 relative on the error rows."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import eval_oracle as EO
+from oracle.gen_eval_golden import synthetic_rows
+from pwclonet_pylidarslam_amd import evaluation as E
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cases():
+    z = np.load(os.path.join(GOLDEN, "eval_cases.npz"))
+    return z, json.loads(str(z["meta"]))["cases"]
+
+
+def test_rows_to_transforms_and_quat2mat(cuda):
+    z, _ = _cases()
+    q = torch.from_numpy(z["quat.q"]).float()
+    rows = torch.cat((torch.tensor([[0.5, -1.0, 2.0]]).expand(q.shape[0], 3), q), dim=1).contiguous().to(cuda)
+    T = E.rows_to_transforms(rows).cpu().numpy()
+    for i in range(q.shape[0]):
+        R = EO.quat2mat(q[i].double().numpy())                 # fp32 row values, fp64 arithmetic
+        np.testing.assert_allclose(T[i, :3, :3], R, rtol=0, atol=1e-15)
+        np.testing.assert_array_equal(T[i, :3, 3], [0.5, -1.0, 2.0])
+        np.testing.assert_array_equal(T[i, 3], [0, 0, 0, 1])
+    Ti = E.rows_to_transforms(rows, invert=True).cpu().numpy()
+    np.testing.assert_allclose(Ti @ T, np.tile(np.eye(4), (q.shape[0], 1, 1)), rtol=0, atol=1e-14)
+    # a strided view: level-1 rows of a (B,4,7) pose_params tensor, no copy
+    pp = torch.zeros(q.shape[0], 4, 7, device=cuda)
+    pp[:, 0, :] = rows
+    np.testing.assert_array_equal(E.rows_to_transforms(pp[:, 0, :]).cpu().numpy(), T)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        E.rows_to_transforms(rows.cpu())
+
+
+def test_evaluator_matches_reference_values(cuda):
+    """All three synthetic sequences through ONE evaluator (batches of 64 frame pairs, interleaved sequences, shuffled
+    frame order inside a batch): trajectories and KITTI numbers equal the reference's."""
+    z, cases = _cases()
+    ev = E.OdometryEvaluator(cuda)
+    rows = {}
+    for sid, (name, cfg) in enumerate(cases.items()):
+        rows[sid] = (name,) + synthetic_rows(**cfg)
+    g = torch.Generator().manual_seed(0)
+    work = [(sid, f) for sid, (_, gt, _) in rows.items() for f in range(gt.shape[0])]
+    perm = torch.randperm(len(work), generator=g).tolist()
+    for b0 in range(0, len(work), 64):
+        chunk = [work[i] for i in perm[b0:b0 + 64]]
+        pose = torch.zeros(len(chunk), 4, 7)
+        gq, gtt = torch.zeros(len(chunk), 4), torch.zeros(len(chunk), 3)
+        for j, (sid, f) in enumerate(chunk):
+            _, gt, pred = rows[sid]
+            pose[j, 0] = torch.from_numpy(pred[f])
+            pose[j, 1:] = 7.0                                          # other levels must be ignored
+            gq[j], gtt[j] = torch.from_numpy(gt[f, 3:]), torch.from_numpy(gt[f, :3])
+        ev.add_batch([s for s, _ in chunk], [f for _, f in chunk], pose.to(cuda), gq.to(cuda), gtt.to(cuda))
+    traj = ev.trajectories()
+    res = ev.evaluate()                                                # through the '%.08f' text round trip, as the reference
+    fast = ev.evaluate(through_text=False)
+    for sid, (name, gt, pred) in rows.items():
+        ap, ag = traj[sid]
+        np.testing.assert_allclose(ap.cpu().numpy(), z[name + ".abs_pred"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(ag.cpu().numpy(), z[name + ".abs_gt"], rtol=0, atol=1e-9)
+        want = z[name + ".ke.seq_err"]
+        got = res[sid]["seq_err"].cpu().numpy()
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        if want.shape[0] == 0:
+            assert res[sid]["ave_t_err"] is None
+            continue
+        np.testing.assert_array_equal(got[:, [0, 3]], want[:, [0, 3]])            # first frames and segment lengths
+        np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=1e-12)              # speed <=> identical last frames
+        np.testing.assert_allclose(got[:, 1:3], want[:, 1:3], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose([res[sid]["ave_t_err"], res[sid]["ave_r_err"]], z[name + ".ke.overall"], rtol=1e-8)
+        for L, t, rr in z[name + ".ke.segment"]:
+            g_ = res[sid]["segment"][int(L)]
+            assert (g_ == [] and np.isnan(t)) or np.allclose(g_, [t, rr], rtol=1e-8)
+        for key, t, rr in z[name + ".ke.speed"]:
+            g_ = res[sid]["speed"][int(key)]
+            assert (g_ == [] and np.isnan(t)) or np.allclose(g_, [t, rr], rtol=1e-8)
+        assert abs(fast[sid]["ave_t_err"] - res[sid]["ave_t_err"]) <= 1e-6 * res[sid]["ave_t_err"]
+        print("\n%s: t_rel %.4f %%  r_rel %.4f deg/100m  (%d segments)" % (
+            name, res[sid]["t_rel_percent"], res[sid]["r_rel_deg_per_100m"], got.shape[0]))
+
+
+def test_eval_odometry_array_functions(cuda):
+    """The mirrors of slam/eval/eval_odometry.py on device tensors against the reference's recorded outputs."""
+    z, cases = _cases()
+    for name in cases:
+        P = torch.from_numpy(z[name + ".abs_pred"]).to(cuda)
+        G = torch.from_numpy(z[name + ".abs_gt"]).to(cuda)
+        rel = E.compute_relative_poses(P)
+        np.testing.assert_allclose(rel.cpu().numpy(), z[name + ".eo.rel_of_abs"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(E.compute_absolute_poses(rel).cpu().numpy(), z[name + ".eo.abs_of_rel"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(E.compute_cumulative_trajectory_length(G).cpu().numpy(), z[name + ".eo.cumlen"], rtol=1e-12)
+        errs = E.calcSequenceErrors(P, G)
+        want = z[name + ".eo.seq_err"]
+        assert len(errs) == want.shape[0]
+        for e, w in zip(errs, want):
+            assert e["first_frame"] == int(w[0]) and e["last_frame"] == int(w[5]) and e["segment"] == w[3]
+            assert abs(e["r_err"] - w[1]) <= 1e-7 * abs(w[1]) + 1e-12 and abs(e["tr_err"] - w[2]) <= 1e-7 * abs(w[2]) + 1e-12
+        km = E.compute_kitti_metrics(P, G)
+        if want.shape[0]:
+            np.testing.assert_allclose(km[:2], z[name + ".eo.kitti"], rtol=1e-8)
+        else:
+            assert km == (None, None)
+        np.testing.assert_allclose(E.compute_ate(rel, E.compute_relative_poses(G)), z[name + ".eo.ate"], rtol=1e-9)
+        np.testing.assert_allclose(E.compute_are(rel, E.compute_relative_poses(G)), z[name + ".eo.are"], rtol=1e-7)

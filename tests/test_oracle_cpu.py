@@ -246,3 +246,49 @@ def test_preprocess_oracle_kitti360_known_values():
     xyz, keep = kitti360_filter(pts, 35.0)
     assert keep.tolist() == [True, False, True, False, True, False]
     assert xyz.dtype == np.float32 and xyz.shape == (6, 3)
+
+
+# ---- odometry evaluation: oracle/eval_oracle.py against values recorded from the imported
+# ---- reference (oracle/gen_eval_golden.py -> tests/golden/eval_cases.npz)
+
+def _eval_cases():
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval_cases.npz"))
+    return z, json.loads(str(z["meta"]))["cases"]
+
+
+def test_eval_oracle_matches_reference_values():
+    from oracle import eval_oracle as EO
+    from oracle.gen_eval_golden import synthetic_rows
+    z, cases = _eval_cases()
+    for q, R in zip(z["quat.q"], z["quat.R"]):
+        assert np.array_equal(EO.quat2mat(q), R)                       # same expressions, bitwise
+    assert np.array_equal(EO.quat2mat(np.array([1e-5, 2e-5, 0, 0])), np.eye(3))
+    for name, cfg in cases.items():
+        gt_rows, pred_rows = synthetic_rows(**cfg)
+        r = EO.kitti_odom_eval(pred_rows, gt_rows)
+        np.testing.assert_allclose(r["abs_pred"], z[name + ".abs_pred"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(r["abs_gt"], z[name + ".abs_gt"], rtol=0, atol=1e-12)
+        P, G = z[name + ".abs_pred"], z[name + ".abs_gt"]
+        np.testing.assert_allclose(EO.compute_relative_poses(P), z[name + ".eo.rel_of_abs"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(EO.compute_absolute_poses(EO.compute_relative_poses(P)), z[name + ".eo.abs_of_rel"],
+                                   rtol=0, atol=1e-10)
+        np.testing.assert_allclose(EO.compute_cumulative_trajectory_length(G), z[name + ".eo.cumlen"], rtol=1e-14)
+        np.testing.assert_allclose(EO.calc_sequence_errors_arrays(P, G), z[name + ".eo.seq_err"], rtol=1e-9, atol=1e-15)
+        np.testing.assert_allclose(EO.compute_ate(EO.compute_relative_poses(P), EO.compute_relative_poses(G)),
+                                   z[name + ".eo.ate"], rtol=1e-12)
+        np.testing.assert_allclose(EO.compute_are(EO.compute_relative_poses(P), EO.compute_relative_poses(G)),
+                                   z[name + ".eo.are"], rtol=1e-12)
+        np.testing.assert_allclose(r["seq_err"], z[name + ".ke.seq_err"], rtol=1e-12, atol=1e-15)
+        if r["seq_err"].shape[0]:
+            np.testing.assert_allclose([r["ave_t_err"], r["ave_r_err"]], z[name + ".ke.overall"], rtol=1e-12)
+            seg = z[name + ".ke.segment"]
+            for L, t, rr in seg:
+                got = r["segment"][int(L)]
+                assert (got == [] and np.isnan(t)) or np.allclose(got, [t, rr], rtol=1e-12)
+            for key, t, rr in z[name + ".ke.speed"]:
+                got = r["speed"][int(key)]
+                assert (got == [] and np.isnan(t)) or np.allclose(got, [t, rr], rtol=1e-12)
+        else:
+            assert z[name + ".ke.seq_err"].shape[0] == 0 and r["ave_t_err"] is None
