@@ -2,8 +2,14 @@
 reference (tests/golden/eval_cases.npz, oracle/gen_eval_golden.py) and against the NumPy oracle.
 
 fp64 throughout; the kernels compose SE(3) transforms with a wave-level scan (a different association of the same
-products than the reference's sequential loop) and invert [R t] in closed form, so the bound is rounding-level:
-1e-9 absolute on poses (trajectories of ~1 km), 1e-7 relative on the error rows."""
+products than the reference's sequential loop) and invert [R t] in closed form, so against the NumPy oracle evaluated
+in float64 the bound is rounding-level: 1e-9 absolute on poses (trajectories of ~1 km), 1e-7 relative on error rows.
+
+Against the values recorded from the imported reference the bound is the REFERENCE's own noise: its pose rows are
+float32 and, under NumPy >= 2 (this container), ``quat2mat`` and the per-frame ``np.linalg.inv`` (train.py:873-878) run
+in float32 (under the NumPy 1.x it was written for, in a float32/float64 mixture), i.e. every frame's matrix carries
+~1e-7 of error that the trajectory accumulates (measured here: 2.5e-4 m after ~1 km).  The kernels use float64 from the
+float32 row values on; bounds against the recorded values: 1e-3 m on poses, 1e-3 relative on the averaged errors."""
 import json
 import os
 
@@ -32,6 +38,7 @@ def test_rows_to_transforms_and_quat2mat(cuda):
     for i in range(q.shape[0]):
         R = EO.quat2mat(q[i].double().numpy())                 # fp32 row values, fp64 arithmetic
         np.testing.assert_allclose(T[i, :3, :3], R, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(T[i, :3, :3], z["quat.R"][i], rtol=0, atol=1e-6)   # recorded from float64 quaternions
         np.testing.assert_array_equal(T[i, :3, 3], [0.5, -1.0, 2.0])
         np.testing.assert_array_equal(T[i, 3], [0, 0, 0, 1])
     Ti = E.rows_to_transforms(rows, invert=True).cpu().numpy()
@@ -70,24 +77,37 @@ def test_evaluator_matches_reference_values(cuda):
     fast = ev.evaluate(through_text=False)
     for sid, (name, gt, pred) in rows.items():
         ap, ag = traj[sid]
-        np.testing.assert_allclose(ap.cpu().numpy(), z[name + ".abs_pred"], rtol=0, atol=1e-9)
-        np.testing.assert_allclose(ag.cpu().numpy(), z[name + ".abs_gt"], rtol=0, atol=1e-9)
-        want = z[name + ".ke.seq_err"]
+        # (1) against the NumPy oracle in float64: rounding-level
+        o = EO.kitti_odom_eval(pred.astype(np.float64), gt.astype(np.float64))
+        np.testing.assert_allclose(ap.cpu().numpy(), o["abs_pred"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(ag.cpu().numpy(), o["abs_gt"], rtol=0, atol=1e-9)
         got = res[sid]["seq_err"].cpu().numpy()
+        assert got.shape == o["seq_err"].shape, (name, got.shape, o["seq_err"].shape)
+        # (2) against the values recorded from the imported reference (float32 per-frame matrices, see the docstring)
+        np.testing.assert_allclose(ap.cpu().numpy(), z[name + ".abs_pred"], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(ag.cpu().numpy(), z[name + ".abs_gt"], rtol=0, atol=1e-3)
+        want = z[name + ".ke.seq_err"]
         assert got.shape == want.shape, (name, got.shape, want.shape)
         if want.shape[0] == 0:
             assert res[sid]["ave_t_err"] is None
             continue
-        np.testing.assert_array_equal(got[:, [0, 3]], want[:, [0, 3]])            # first frames and segment lengths
-        np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=1e-12)              # speed <=> identical last frames
-        np.testing.assert_allclose(got[:, 1:3], want[:, 1:3], rtol=1e-7, atol=1e-12)
-        np.testing.assert_allclose([res[sid]["ave_t_err"], res[sid]["ave_r_err"]], z[name + ".ke.overall"], rtol=1e-8)
-        for L, t, rr in z[name + ".ke.segment"]:
+        np.testing.assert_array_equal(got[:, [0, 3]], o["seq_err"][:, [0, 3]])    # first frames and segment lengths
+        np.testing.assert_allclose(got[:, 4], o["seq_err"][:, 4], rtol=1e-12)      # speed <=> identical last frames
+        np.testing.assert_allclose(got[:, 1:3], o["seq_err"][:, 1:3], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose([res[sid]["ave_t_err"], res[sid]["ave_r_err"]], [o["ave_t_err"], o["ave_r_err"]],
+                                   rtol=1e-8)
+        for L, v in o["segment"].items():
             g_ = res[sid]["segment"][int(L)]
-            assert (g_ == [] and np.isnan(t)) or np.allclose(g_, [t, rr], rtol=1e-8)
-        for key, t, rr in z[name + ".ke.speed"]:
+            assert (g_ == [] and v == []) or np.allclose(g_, v, rtol=1e-8)
+        for key, v in o["speed"].items():
             g_ = res[sid]["speed"][int(key)]
-            assert (g_ == [] and np.isnan(t)) or np.allclose(g_, [t, rr], rtol=1e-8)
+            assert (g_ == [] and v == []) or np.allclose(g_, v, rtol=1e-8)
+        np.testing.assert_array_equal(got[:, [0, 3]], want[:, [0, 3]])
+        np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=1e-12)
+        np.testing.assert_allclose([res[sid]["ave_t_err"], res[sid]["ave_r_err"]], z[name + ".ke.overall"], rtol=1e-3)
+        print("\n%s vs recorded reference values: ave_t_err rel diff %.2e, ave_r_err rel diff %.2e, max pose diff %.2e m" % (
+            name, abs(res[sid]["ave_t_err"] / z[name + ".ke.overall"][0] - 1), abs(res[sid]["ave_r_err"] / z[name + ".ke.overall"][1] - 1),
+            np.abs(ap.cpu().numpy() - z[name + ".abs_pred"]).max()))
         assert abs(fast[sid]["ave_t_err"] - res[sid]["ave_t_err"]) <= 1e-6 * res[sid]["ave_t_err"]
         print("\n%s: t_rel %.4f %%  r_rel %.4f deg/100m  (%d segments)" % (
             name, res[sid]["t_rel_percent"], res[sid]["r_rel_deg_per_100m"], got.shape[0]))
