@@ -47,6 +47,12 @@ int pwclo_last_error(void);
 const char *pwclo_last_error_message(void);
 void pwclo_clear_error(void);
 
+/* Developer tool: per-workgroup trace of the kernels on the fused forward path.  records: device buffer of
+ * `capacity` 32-byte records {u64 t0, t1 (100 MHz constant clock); u32 kernel id, block, blocks in grid, hw id};
+ * count: device u32 the kernels bump (zero it first).  records == NULL switches the trace off (the default).
+ * Synchronous (writes device symbols); not for use under graph capture. */
+void pwclo_trace_enable(void *records, void *count, unsigned capacity);
+
 #define PWCLO_EINVAL 10001  /* argument outside what the kernels support (message says which) */
 /* Reported by a RUNNING kernel (not at launch): the cooperative large-cloud sampler gave up waiting for a
  * peer workgroup.  Kernels post such codes into a pinned word the library owns; pwclo_last_error() reads it

@@ -10,7 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpwclo_hip.so")
+# PWCLO_TRACE_LIB=1 (tools/wgtrace.py sets it) loads the developer variant built with the workgroup-trace hooks
+LIB_PATH = os.path.join(_HERE, "lib", "libpwclo_hip_trace.so" if os.environ.get("PWCLO_TRACE_LIB", "0") != "0"
+                        else "libpwclo_hip.so")
 
 _F = ctypes.c_void_p  # device pointers travel as integers
 _i = ctypes.c_int
@@ -23,6 +25,7 @@ SIGNATURES = {
     "pwclo_last_error": ([], _i),
     "pwclo_last_error_message": ([], ctypes.c_char_p),
     "pwclo_clear_error": ([], None),
+    "pwclo_trace_enable": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint], None),
     "gather_points_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F], None),
     "gather_points_grad_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F], None),
     "furthest_point_sampling_kernel_wrapper": ([_i, _i, _i, _F, _F, _F], None),

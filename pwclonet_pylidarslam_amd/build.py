@@ -20,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libpwclo_hip.so")
+LIB_TRACE = os.path.join(HERE, "lib", "libpwclo_hip_trace.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
@@ -42,12 +43,12 @@ def _newest_header_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+def _compile(src, force, trace=False):
+    obj = os.path.join(OBJ + ("_trace" if trace else ""), os.path.basename(src)[:-4] + ".o")
     stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
         os.path.getmtime(src), _newest_header_mtime())
     if stale:
-        cmd = [hipcc()] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc()] + FLAGS + (["-DPWCLO_TRACE"] if trace else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -56,20 +57,23 @@ def _compile(src, force):
     return obj, stale
 
 
-def build(force=False, jobs=None):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, jobs=None, trace=False):
+    """trace=True builds the developer variant lib/libpwclo_hip_trace.so (-DPWCLO_TRACE: per-workgroup trace hooks,
+    tools/wgtrace.py); the product library never carries them."""
+    os.makedirs(OBJ + ("_trace" if trace else ""), exist_ok=True)
+    lib = LIB_TRACE if trace else LIB
     srcs = sources()
     jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
     with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
-        results = list(ex.map(lambda s: _compile(s, force), srcs))
+        results = list(ex.map(lambda s: _compile(s, force, trace), srcs))
     objs = [o for o, _ in results]
-    if force or any(st for _, st in results) or not os.path.exists(LIB):
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if force or any(st for _, st in results) or not os.path.exists(lib):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, trace="--trace" in sys.argv))

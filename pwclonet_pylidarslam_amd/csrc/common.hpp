@@ -38,8 +38,73 @@ static inline int ref_opt_n_threads(int work_size) {
   return p;
 }
 
+// ---- workgroup trace (developer tool, off unless pwclo_trace_enable() was called) ---------------------------
+// rocprofv3's kernel trace serialises the pipelined run (3.7 ms per step instead of 2.26), so it cannot show how
+// kernels of the four in-flight batches share the chip.  With the trace enabled every workgroup of the kernels on
+// the fused forward path appends one record (kernel id, block, start / end of the constant 100 MHz clock,
+// hardware id) to a buffer the caller owns; tools/wgtrace.py turns that into per-kernel CU-time and a concurrency
+// timeline of the REAL pipelined run.  Cost when off: one pointer test per workgroup.
+struct TraceRec { unsigned long long t0, t1; unsigned kernel, block, nblocks, hw; };   // 32 bytes
+struct TraceBuf { TraceRec *rec; unsigned *count; unsigned cap; };
+enum TraceKernel : unsigned {
+  TK_INGEST = 1, TK_FPS = 2, TK_KNN = 3, TK_KNN_BUILD = 4, TK_KNN_PRUNED = 5, TK_LINEAR = 6, TK_SA_H = 7, TK_UPCONV_H = 8,
+  TK_UPCONV_LANE = 9, TK_CV_A1_H = 10, TK_CV_A2 = 11, TK_CV_A2_DENSE6 = 12, TK_CV_A2_LANE6 = 13, TK_CV_B_H = 14,
+  TK_POINTWISE = 15, TK_POSE_HEAD = 16, TK_WARP = 17, TK_OTHER = 18
+};
+void trace_set_fused_layers(const TraceBuf &b);
+void trace_set_fused_hoisted(const TraceBuf &b);
+void trace_set_knn(const TraceBuf &b);
+void trace_set_sampling(const TraceBuf &b);
+void trace_set_warp(const TraceBuf &b);
+
 // ---- device helpers ------------------------------------------------------------------------
 #if defined(__HIPCC__)
+
+// One copy per translation unit (no relocatable device code in this build); the TU's trace_set_*() fills it.
+static __device__ __attribute__((unused)) TraceBuf g_trace = {nullptr, nullptr, 0u};
+#define PWCLO_TRACE_TU(name)                                                                   \
+  namespace pwclo {                                                                            \
+  void trace_set_##name(const TraceBuf &b) {                                                   \
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &b, sizeof(TraceBuf), 0, hipMemcpyHostToDevice); \
+  }                                                                                            \
+  }
+
+#if !defined(PWCLO_TRACE)
+// The product library is built WITHOUT the hooks: even a dormant hook changes register allocation (the level-1
+// sampler went from 79 to 120 VGPRs and the step from 2.26 to 2.29 ms).  `python -m pwclonet_pylidarslam_amd.build
+// --trace` builds lib/libpwclo_hip_trace.so with -DPWCLO_TRACE for tools/wgtrace.py.
+struct TraceScope {
+  __device__ __forceinline__ explicit TraceScope(unsigned, unsigned = 0u) {}
+};
+#else
+struct TraceScope {
+  unsigned long long t0;
+  unsigned kid;
+  bool on;
+  // sample_mask: record only workgroups with (blockIdx.x & sample_mask) == 0 (kernels with ~1e5 tiny workgroups
+  // per step would otherwise perturb the run they are tracing); the tool scales by the sampling rate.
+  __device__ __forceinline__ explicit TraceScope(unsigned k, unsigned sample_mask = 0u) : t0(0), kid(k) {
+    on = threadIdx.x == 0 && threadIdx.y == 0 && g_trace.rec != nullptr && (blockIdx.x & sample_mask) == 0u;
+    if (on) t0 = wall_clock64();
+  }
+  __device__ __forceinline__ ~TraceScope() {
+    if (on) {
+      const unsigned long long t1 = wall_clock64();
+      const unsigned slot = atomicAdd(g_trace.count, 1u);
+      if (slot < g_trace.cap) {
+        TraceRec r;
+        r.t0 = t0; r.t1 = t1; r.kernel = kid;
+        r.block = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        r.nblocks = gridDim.x * gridDim.y * gridDim.z;
+        r.hw = (unsigned)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 8 << 6 | 4) |            /* HW_ID: cu_id[11:8] */
+               ((unsigned)__builtin_amdgcn_s_getreg((3 - 1) << 11 | 13 << 6 | 4) << 4) |     /* HW_ID: se_id[15:13] */
+               ((unsigned)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 8);      /* XCC_ID[3:0] */
+        g_trace.rec[slot] = r;
+      }
+    }
+  }
+};
+#endif
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 

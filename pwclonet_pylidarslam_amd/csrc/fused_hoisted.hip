@@ -13,6 +13,8 @@
 
 #include "mlp_core.hpp"
 
+PWCLO_TRACE_TU(fused_hoisted)
+
 namespace pwclo {
 
 static int fh_tuning(const char *name, int dflt) {
@@ -93,6 +95,7 @@ __device__ __forceinline__ void linear_tiles(const LinJob &jb, const float *lds_
 }
 
 __global__ __launch_bounds__(LIN_WAVES * 64) void linear_jobs_kernel(LinArgs a) {
+  TraceScope trace_scope_(TK_LINEAR);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   const LinJob jb = a.job[blockIdx.y];
   stage_weights(lds_w, jb.w, layer_floats(jb.nbi, jb.nbo));
@@ -115,6 +118,7 @@ struct SAHArgs {
 
 template <int B1, int B2, int B3, int KP, int P, int W, bool XYZ_ONLY, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
+  TraceScope trace_scope_(TK_SA_H);
   constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<BF3>(B1, B2), W3 = layer_floats_any<BF3>(B2, B3);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2 + W3);
@@ -191,6 +195,7 @@ struct UpHArgs {
 
 template <int KP, int P, int W, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
+  TraceScope trace_scope_(TK_UPCONV_H);
   constexpr int B1 = 8, B2 = 4;
   constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<BF3>(B1, B2);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -245,6 +250,7 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
 // running maximum in registers -- no DPP reduction, and every lane stores its own query's row.
 template <int W>
 __global__ __launch_bounds__(W * 64) void upconv_lane_kernel(UpHArgs a) {
+  TraceScope trace_scope_(TK_UPCONV_LANE);
   constexpr int B1 = 8, B2 = 4;
   constexpr int W1 = layer_floats(1, B1);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -314,6 +320,7 @@ struct CVHArgs {
 
 template <int KP, int P, int W, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
+  TraceScope trace_scope_(TK_CV_A1_H);
   constexpr int B1 = 8, B2 = 4, B3 = 4;
   constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<BF3>(B1, B2), W3 = layer_floats_any<BF3>(B2, B3);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -363,6 +370,7 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
 
 template <int KP, int P, int W, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
+  TraceScope trace_scope_(TK_CV_B_H);
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<BF3>(4, 8), W2 = layer_floats_any<BF3>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, WX + W1 + W2);
@@ -503,7 +511,8 @@ extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, in
   SAH_CASE(16, 16, 32, 32, false, 2, 8)     // psa_2
   SAH_CASE(32, 32, 64, 16, false, 1, 16)    // psa_3
   SAH_CASE(64, 64, 128, 16, false, 1, 16)   // psa_4
-  if (tiles_h(b, s, 16, 1) <= 2048) { SAH_CASE(128, 64, 64, 16, false, 1, 4) }   // flow_feature_encoding, coarse
+  static const int coarse_w4 = fh_tuning("PWCLO_COARSE_W4", 1);
+  if (coarse_w4 && tiles_h(b, s, 16, 1) <= 2048) { SAH_CASE(128, 64, 64, 16, false, 1, 4) }   // flow_feature_encoding, coarse
   SAH_CASE(128, 64, 64, 16, false, 1, 16)   // flow_feature_encoding
 #undef SAH_CASE
   set_error(PWCLO_EINVAL, "sa_fused_h: no kernel for mlp=(%d,%d,%d) nsample=%d level0=%d", c1, c2, c3, k, (int)lvl0);
@@ -569,7 +578,8 @@ extern "C" void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xy
   constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(4, 8) + layer_floats(8, 4));
   static bool attr_s = false, attr3 = false, attr3_s = false;
   constexpr int lds3 = 4 * (layer_floats(1, 4) + layer_floats_bf3(4, 8) + layer_floats_bf3(8, 4));
-  const bool small = tiles_h(b, s, 4, 1) <= 2048;
+  static const int coarse_w4 = fh_tuning("PWCLO_COARSE_W4", 1);
+  const bool small = coarse_w4 && tiles_h(b, s, 4, 1) <= 2048;
   PWCLO_REQUIRE_PACKED("cv_fused_b_h", wfmt, packed_floats, lds / 4, lds3 / 4);
   if (wfmt == PWCLO_WFMT_BF16X3 && small) launch_h<4>(cv_b_h_kernel<4, 1, 4, true>, attr3_s, lds3, tiles_h(b, s, 4, 1), a);
   else if (wfmt == PWCLO_WFMT_BF16X3) launch_h<16>(cv_b_h_kernel<4, 1, 16, true>, attr3, lds3, tiles_h(b, s, 4, 1), a);

@@ -17,6 +17,8 @@
 
 #include "mlp_core.hpp"
 
+PWCLO_TRACE_TU(fused_layers)
+
 namespace pwclo {
 
 
@@ -158,6 +160,7 @@ struct PointwiseArgs {
 
 template <int NB0, int NB1, int NB2, int B1, int B2 /*0 = single layer*/, int P, int W>
 __global__ __launch_bounds__(W * 64) void pointwise_kernel(PointwiseArgs a) {
+  TraceScope trace_scope_(TK_POINTWISE);
   constexpr int NBI = NB0 + NB1 + NB2;
   constexpr int W1 = layer_floats(NBI, B1);
   constexpr int W2 = B2 > 0 ? layer_floats(B1, B2) : 0;
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(W * 64) void cv_a1_kernel(CVArgs a) {
 // a2: enc = mlp_conv_xyz_1(geo); w = softmax_k(mlp2_convs([enc | feat])); out = sum_k w * feat.
 template <int KP, int P, int W, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
+  TraceScope trace_scope_(TK_CV_A2);
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<BF3>(8, 8), W2 = layer_floats_any<BF3>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, WX + W1 + W2);
@@ -328,6 +332,7 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
 // cv_a1 writes the per-pixel features densely as (B, S, 6, 64) for this kernel.
 template <int W, bool BF3 = false>
 __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
+  TraceScope trace_scope_(TK_CV_A2_DENSE6);
   constexpr int P = 3;
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<BF3>(8, 8), W2 = layer_floats_any<BF3>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -425,6 +430,7 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
 // for n; out = n / d.  Same values as the direct form up to two extra roundings (1e-7 relative).
 template <int W>
 __global__ __launch_bounds__(W * 64) void cv_a2_lane6_kernel(CVArgs a) {
+  TraceScope trace_scope_(TK_CV_A2_LANE6);
   constexpr int P = 2, PASSES = 3;          // three passes of two neighbour blocks: fits 256 VGPRs without spills
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats(8, 8), W2 = layer_floats(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -613,6 +619,7 @@ __device__ __forceinline__ void quat_mul(const float *a, const float *b, float *
 }
 
 __global__ __launch_bounds__(64 * MP_PARTS) void pose_head_kernel(PoseHeadArgs a) {
+  TraceScope trace_scope_(TK_POSE_HEAD);
   // Pooling layout: a lane owns 4 channels (16-byte loads) of every 4th point of its wave's slice, so a
   // wave-load covers 4 whole 256-byte rows; 64 (wave, point-slot) partials per channel meet in LDS.
   __shared__ float red[4 * MP_PARTS][64];
@@ -759,7 +766,7 @@ extern "C" void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int
     constexpr int lds = 4 * (layer_floats(NBI, A1 / 16) + (A2 > 0 ? layer_floats(A1 / 16, A2 / 16) : 0)); \
     /* few tiles (coarse levels): 4-wave workgroups spread them over 4x more CUs; a 16-wave        \
        workgroup would run 4 tiles back to back on each SIMD while most of the chip idles */        \
-    if (wide && tiles_of(b, s, 1, 1) <= 2048)                                                       \
+    if (wide && fl_tuning("PWCLO_COARSE_W4", 1) && tiles_of(b, s, 1, 1) <= 2048)                    \
       launch_persistent<4>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 4>,      \
                            attr4, lds, tiles_of(b, s, 1, 1), a);                                    \
     else if (wide) launch_persistent<16>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 16>, \
@@ -842,7 +849,7 @@ extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const flo
   // in-lane softmax for the large levels; a coarse level has too few 16-query tiles to fill the chip (measured:
   // 48 us against 31 us for the dense-6 kernel on 4-wave workgroups at S = 256)
   if (kp == 6 && lane6 && t16 > 1024) launch_persistent<8>(cv_a2_lane6_kernel<8>, attrl, lds, t16, a);
-  else if (kp == 6 && t6 <= 2048)   // coarse level: 4-wave workgroups reach twice as many CUs
+  else if (kp == 6 && t6 <= 2048 && fl_tuning("PWCLO_COARSE_W4", 1))   // coarse level: 4-wave workgroups reach twice as many CUs
     launch_persistent<4>(cv_a2_dense6_kernel<4>, attr6s, lds, t6, a);
   else if (kp == 6) launch_persistent<8>(cv_a2_dense6_kernel<8>, attr6, lds, t6, a);
   else if (kp == 32) launch_persistent<8>(cv_a2_kernel<32, 2, 8>, attr32, lds, tiles_of(b, s, 32, 2), a);

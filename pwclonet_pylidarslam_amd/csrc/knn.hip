@@ -25,6 +25,8 @@
 // candidate the exact comparison would keep; false positives only cost a pool slot.
 #include "common.hpp"
 
+PWCLO_TRACE_TU(knn)
+
 namespace pwclo {
 
 constexpr int KNN_WAVES = 4;   // waves per workgroup
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(int n, int s, int K
                                                              const float *__restrict__ new_xyz,
                                                              int *__restrict__ idx,
                                                              float *__restrict__ dist) {
+  TraceScope trace_scope_(TK_KNN, 3u);
   __shared__ u64 pools[KNN_WAVES][QPW][KNN_POOL];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(KB_THREADS) void knn_build_kernel(int n, int nslab,
                                                                const float *__restrict__ xyz,
                                                                float4 *__restrict__ rows,
                                                                float4 *__restrict__ boxes) {
+  TraceScope trace_scope_(TK_KNN_BUILD);
   __shared__ int hist[KB_BINS];      // x histogram, then slab of every x-bin
   __shared__ int hist2[KB_BINS];     // (slab, z-bin) histogram, then row offset of every bin
   __shared__ int cursor[KB_BINS];
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_pruned_kernel(int nblk, in
                                                                     const float *__restrict__ new_xyz,
                                                                     int *__restrict__ idx,
                                                                     float *__restrict__ dist) {
+  TraceScope trace_scope_(TK_KNN_PRUNED, 15u);
   __shared__ u64 pools[KNN_WAVES][KNN_POOL];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;

@@ -23,6 +23,8 @@
 
 #include "common.hpp"
 
+PWCLO_TRACE_TU(sampling)
+
 namespace pwclo {
 
 constexpr int PRI_SHIFT = 23;  // k div bs < 2^23
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
                                                     float *__restrict__ new_xyz,
                                                     int *__restrict__ tie_out, int tie_iters,
                                                     const int *__restrict__ prefix_in) {
+  TraceScope trace_scope_(TK_FPS);
   constexpr int PPT = I << E;
   if (prefix_in != nullptr && prefix_in[blockIdx.x * FPS_CHAIN_INTS] == 0) {       // workgroup-uniform
     const int *rec = prefix_in + blockIdx.x * FPS_CHAIN_INTS;

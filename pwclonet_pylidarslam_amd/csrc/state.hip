@@ -87,6 +87,20 @@ int pwclo_last_error(void) {
   return pwclo::t_err;
 }
 const char *pwclo_last_error_message(void) { return pwclo::t_msg; }
+void pwclo_trace_enable(void *records, void *count, unsigned capacity) {
+#if !defined(PWCLO_TRACE)
+  if (records != nullptr)
+    pwclo::set_error(PWCLO_EINVAL, "this library was built without the workgroup-trace hooks "
+                                   "(python -m pwclonet_pylidarslam_amd.build --trace builds the traced variant)");
+#endif
+  pwclo::TraceBuf b{reinterpret_cast<pwclo::TraceRec *>(records), reinterpret_cast<unsigned *>(count),
+                    records ? capacity : 0u};
+  pwclo::trace_set_fused_layers(b);
+  pwclo::trace_set_fused_hoisted(b);
+  pwclo::trace_set_knn(b);
+  pwclo::trace_set_sampling(b);
+  pwclo::trace_set_warp(b);
+}
 void pwclo_clear_error(void) {
   pwclo::t_err = 0;
   pwclo::t_msg[0] = 0;

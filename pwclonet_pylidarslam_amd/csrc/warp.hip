@@ -8,6 +8,8 @@
 
 #include "common.hpp"
 
+PWCLO_TRACE_TU(warp)
+
 namespace pwclo {
 
 struct quat { float w, x, y, z; };
@@ -27,6 +29,7 @@ __global__ __launch_bounds__(256) void quat_warp_kernel(int n, const float *__re
                                                         const float *__restrict__ q,
                                                         const float *__restrict__ t,
                                                         float *__restrict__ out) {
+  TraceScope trace_scope_(TK_WARP);
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
@@ -50,6 +53,7 @@ __global__ __launch_bounds__(256) void quat_warp_kernel(int n, const float *__re
 __global__ __launch_bounds__(256) void ingest_pairs_kernel(int bsz, int n, const float *__restrict__ f1,
                                                            const float *__restrict__ f2,
                                                            float *__restrict__ out) {
+  TraceScope trace_scope_(TK_INGEST, 15u);
   const int b = blockIdx.y;               // 0 .. 2*bsz-1
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;

@@ -6,6 +6,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pwclonet_pylidarslam_amd
+pwclonet_pylidarslam_amd.configure_hw_queues(8)
 import bench
 from pwclonet_pylidarslam_amd import fused, _lib
 from pwclonet_pylidarslam_amd.pwclonet import PWCLONet
@@ -38,7 +39,11 @@ def run(tag, inflight):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 40
     print(f"{tag:24s} inflight={inflight}: {dt*1e3:6.3f} ms/step  {32/dt:7.0f} pairs/s", flush=True)
 
-for inflight in (4,):
+only_mlp = "--mlp-only" in sys.argv
+for inflight in ((1, 2, 3, 4, 6) if only_mlp else (4,)):
+    if only_mlp:
+        fused.fps_with_xyz, fused.knn = fake_fps, fake_knn; run("no FPS, no knn (MLP+glue)", inflight)
+        continue
     fused.fps_with_xyz, fused.knn = orig["fps"], orig["knn"]
     run("full", inflight)
     fused.fps_with_xyz = fake_fps; run("no FPS", inflight); fused.fps_with_xyz = orig["fps"]
