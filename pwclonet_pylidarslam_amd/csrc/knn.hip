@@ -23,6 +23,8 @@
 // bound = key_K^2 * (1 + 2^-20): strictly above every t whose rounded key can still be <= key_K
 // (sqrt and the +1e-8 add each move t by < 2^-23 relative), so the filter never drops a
 // candidate the exact comparison would keep; false positives only cost a pool slot.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 PWCLO_TRACE_TU(knn)
@@ -59,10 +61,9 @@ constexpr u64 keepmin_mask(int size, int stride, bool desc) {
   return m;
 }
 
-// One compare-exchange step on a packed key held as (lo, hi).
-template <int SIZE, int S, bool DESC>
-__device__ __forceinline__ void cmpx_step(unsigned &lo, unsigned &hi) {
-  constexpr u64 KEEPMIN = keepmin_mask(SIZE, S, DESC);
+// One compare-exchange step on a packed key held as (lo, hi); KEEPMIN = lanes that keep the minimum.
+template <u64 KEEPMIN, int S>
+__device__ __forceinline__ void cmpx_mask(unsigned &lo, unsigned &hi) {
   if (S <= 8) {
     const unsigned olo = xor_dpp<S>(lo), ohi = xor_dpp<S>(hi);
     const u64 mine = ((u64)hi << 32) | lo, other = ((u64)ohi << 32) | olo;
@@ -90,6 +91,11 @@ __device__ __forceinline__ void cmpx_step(unsigned &lo, unsigned &hi) {
     lo = takeU ? Ulo : Llo;
     hi = takeU ? Uhi : Lhi;
   }
+}
+
+template <int SIZE, int S, bool DESC>
+__device__ __forceinline__ void cmpx_step(unsigned &lo, unsigned &hi) {
+  cmpx_mask<keepmin_mask(SIZE, S, DESC), S>(lo, hi);
 }
 
 template <int SIZE, bool DESC>
@@ -543,6 +549,212 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_pruned_kernel(int nblk, in
   }
 }
 
+
+// =====================================================================================================
+// Several queries per wave ("rows"): the pruned search for K <= 32.
+//
+// A bitonic network costs the same number of steps whatever the number of independent sequences packed into the
+// wave, and knn_pruned_kernel spends most of its instructions in 64-wide sorts (21 + 6 steps per fold) to select
+// 4..32 neighbours.  Here a wave serves Q = 64 / L queries, L = 16 (K <= 16) or 32 (K <= 32): query r owns lanes
+// [r*L, (r+1)*L) -- its sorted best list (one packed (key, index) per lane), its block lower bounds (block
+// p, p+L, ... on lane p), its LDS pool.  All rows run the same instruction stream on their own data:
+//   * every row walks ITS blocks in order of increasing lower bound (nearest first), L candidates per sub-step,
+//     until the next block's bound cannot beat its K-th key;
+//   * survivors (t < row bound) are appended to the row's pool; a pool holding >= L entries (or the first K while
+//     the bound is still infinite) is folded in with an L-wide sort (10 / 15 steps) + L-wide merge (4 / 5 steps);
+//   * at the end of a block the few survivors a tight bound lets through are INSERTED one at a time (position =
+//     number of smaller list entries, lanes above it shift up by one: ~12 instructions for all rows at once)
+//     instead of sorted.
+// Keys, tie rule (lower index first), the conservative filter bound and the block-skip margin are those of
+// knn_pruned_kernel, so the output is the same list, bit for bit (tests/test_gpu_ops.py::test_knn_*).
+// =====================================================================================================
+template <int L>
+constexpr u64 keepmin_rows(int size, int stride, bool desc) {   // like keepmin_mask, every row sorted the same way
+  u64 m = 0;
+  for (int l = 0; l < 64; ++l) {
+    const bool lower = (l & stride) == 0;
+    bool up = size >= L ? true : ((l & size) == 0);
+    if (desc) up = !up;
+    if (lower == up) m |= 1ull << l;
+  }
+  return m;
+}
+template <int L, int SIZE, bool DESC>
+__device__ __forceinline__ void merge_stage_rows(unsigned &lo, unsigned &hi) {   // strides SIZE/2 .. 1, SIZE <= L
+  if (SIZE >= 32) cmpx_mask<keepmin_rows<L>(SIZE, 16, DESC), 16>(lo, hi);
+  if (SIZE >= 16) cmpx_mask<keepmin_rows<L>(SIZE, 8, DESC), 8>(lo, hi);
+  if (SIZE >= 8) cmpx_mask<keepmin_rows<L>(SIZE, 4, DESC), 4>(lo, hi);
+  if (SIZE >= 4) cmpx_mask<keepmin_rows<L>(SIZE, 2, DESC), 2>(lo, hi);
+  cmpx_mask<keepmin_rows<L>(SIZE, 1, DESC), 1>(lo, hi);
+}
+template <int L, bool DESC>
+__device__ __forceinline__ void sort_rows(unsigned &lo, unsigned &hi) {          // every row of L lanes, 10 / 15 steps
+  merge_stage_rows<L, 2, DESC>(lo, hi);
+  merge_stage_rows<L, 4, DESC>(lo, hi);
+  merge_stage_rows<L, 8, DESC>(lo, hi);
+  merge_stage_rows<L, 16, DESC>(lo, hi);
+  if (L >= 32) merge_stage_rows<L, 32, DESC>(lo, hi);
+}
+template <int L>
+__device__ __forceinline__ unsigned row_min_u32(unsigned v) {                    // all lanes of a row get the row's min
+  v = row16_allreduce_u32(v, OpMinU32());
+  if (L == 32) {
+    const unsigned o = (unsigned)__shfl_xor((int)v, 16, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+template <int L, int R>
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_rows_kernel(int nblk, int s, int K,
+                                                                  const float4 *__restrict__ rows,
+                                                                  const float4 *__restrict__ boxes,
+                                                                  const float *__restrict__ new_xyz,
+                                                                  int *__restrict__ idx,
+                                                                  float *__restrict__ dist) {
+  TraceScope trace_scope_(TK_KNN_PRUNED, 15u);
+  constexpr int Q = 64 / L, SUB = 64 / L;
+  constexpr unsigned LMASK = L == 32 ? 0xFFFFFFFFu : 0xFFFFu;
+  constexpr int INS_MAX = L / 4;            // up to this many pooled survivors per row: insert; more: sort
+  __shared__ u64 pools[KNN_WAVES][Q][2 * L];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int q0 = (blockIdx.x * KNN_WAVES + wave) * Q;
+  if (q0 >= s) return;                      // wave-uniform; no workgroup barrier below
+  const int row = lane / L, p = lane % L;
+  const int rowbase = lane - p;             // first lane of this row
+  const int q = q0 + row;
+  const bool qvalid = q < s;
+  const float INF = __int_as_float(0x7f800000);
+  const float *qp = new_xyz + ((size_t)b * s + (qvalid ? q : s - 1)) * 3;
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  const float4 *crow = rows + (size_t)b * nblk * 64;
+  const float4 *cbox = boxes + (size_t)b * nblk * 2;
+  u64 *pool = pools[wave][row];
+
+  float lb[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int blk = r * L + p;
+    float v = INF;
+    if (blk < nblk) {
+      const float4 l = cbox[blk * 2], h = cbox[blk * 2 + 1];
+      const float dx = fmaxf(fmaxf(l.x - qx, qx - h.x), 0.f);
+      const float dy = fmaxf(fmaxf(l.y - qy, qy - h.y), 0.f);
+      const float dz = fmaxf(fmaxf(l.z - qz, qz - h.z), 0.f);
+      v = ((dx * dx + dy * dy) + dz * dz) * 0.999996f;   // 1 - 2^-18: strictly conservative (knn_pruned_kernel)
+      if (!(v < INF)) v = INF;                           // empty boxes give inf or NaN: never visited
+    }
+    lb[r] = v;
+  }
+
+  float bound = INF;
+  unsigned bl = 0xFFFFFFFFu, bh = 0xFFFFFFFFu;
+  int cnt = 0;
+
+  auto row_bits = [&](u64 mask) -> unsigned { return (unsigned)(mask >> rowbase) & LMASK; };
+  auto refresh_bound = [&]() {
+    const unsigned kbits = (unsigned)__builtin_amdgcn_ds_bpermute((rowbase + K - 1) << 2, (int)bh);   // row's K-th key
+    if (kbits != 0xFFFFFFFFu) {
+      const float key_k = __uint_as_float(kbits);
+      bound = (key_k * key_k) * 1.000001f;
+    }
+  };
+  // fold min(cnt, L) pooled survivors of every row into its best list with an L-wide sort
+  auto fold_sort = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int c = cnt;
+    const u64 e = p < c ? pool[p] : KNN_EMPTY;
+    const u64 rest = (p + L < c) ? pool[p + L] : KNN_EMPTY;
+    unsigned lo = (unsigned)e, hi = (unsigned)(e >> 32);
+    if (p < c) hi = __float_as_uint(sqrtf(__uint_as_float(hi) + 1e-8f));   // exact key (oracle order)
+    sort_rows<L, true>(lo, hi);                            // survivors, descending
+    const u64 nv = ((u64)hi << 32) | lo, bv = ((u64)bh << 32) | bl;
+    const bool tk = nv < bv;                               // lane-wise min with the ascending list: bitonic
+    bl = tk ? lo : bl;
+    bh = tk ? hi : bh;
+    merge_stage_rows<L, L, false>(bl, bh);                 // ... ascending again
+    __builtin_amdgcn_wave_barrier();
+    const int left = c > L ? c - L : 0;
+    if (p < left) pool[p] = rest;
+    cnt = left;
+    refresh_bound();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  // insert every row's pooled survivors one at a time (few of them: the bound is already tight)
+  auto insert_all = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; __ballot(i < cnt) != 0ull; ++i) {
+      const bool have = i < cnt;
+      const u64 e = have ? pool[i] : KNN_EMPTY;            // same address for the whole row: broadcast read
+      const unsigned elo = (unsigned)e;
+      const unsigned ehi = have ? __float_as_uint(sqrtf(__uint_as_float((unsigned)(e >> 32)) + 1e-8f)) : 0xFFFFFFFFu;
+      const u64 E = ((u64)ehi << 32) | elo, mine = ((u64)bh << 32) | bl;
+      const int pos = (int)__popc(row_bits(__ballot(mine < E)));   // the list is ascending: a prefix of the row
+      const unsigned plo = dpp_u32<0x138>(bl), phi = dpp_u32<0x138>(bh);    // wave_shr:1 -- value of lane - 1
+      if (p == pos) { bl = elo; bh = ehi; }
+      else if (p > pos) { bl = plo; bh = phi; }
+    }
+    cnt = 0;
+    refresh_bound();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  // unvisited block of this row with the smallest lower bound, if it can still hold a neighbour (-1 otherwise)
+  auto next_block = [&]() -> int {
+    float m = lb[0];
+    int mb = p;
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+      if (lb[r] < m) { m = lb[r]; mb = r * L + p; }
+    const unsigned mv = row_min_u32<L>(__float_as_uint(m));            // lb >= 0: the bit patterns order
+    const unsigned cb = __float_as_uint(m) == mv ? (unsigned)mb : 0xFFFFFFFFu;
+    const unsigned blk = row_min_u32<L>(cb);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (blk == (unsigned)(r * L + p)) lb[r] = INF;                   // visited
+    return __uint_as_float(mv) < bound ? (int)blk : -1;
+  };
+
+  int cur = next_block();
+  if (!qvalid) cur = -1;
+  while (true) {
+    const bool active = cur >= 0;
+    if (__ballot(active) == 0ull) break;
+    const float4 *base = crow + (size_t)(active ? cur : 0) * 64 + p;
+#pragma unroll
+    for (int sub = 0; sub < SUB; ++sub) {
+      float4 c = make_float4(INF, 0.f, 0.f, 0.f);
+      if (active) c = base[sub * L];
+      const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+      const float t = (dx * dx + dy * dy) + dz * dz;               // padding rows have x = inf -> t = inf
+      const bool pass = active && t < bound;
+      const u64 mask = __ballot(pass);
+      if (mask != 0ull) {
+        const unsigned rb = row_bits(mask);
+        if (pass) pool[cnt + (int)__popc(rb & ((1u << p) - 1u))] = ((u64)__float_as_uint(t) << 32) | (u64)__float_as_uint(c.w);
+        cnt += (int)__popc(rb);
+        if (__ballot(cnt >= L || (bound == INF && cnt >= K)) != 0ull) fold_sort();
+      }
+    }
+    // end of the block: settle the survivors so that the bound is current, then move on
+    while (__ballot(cnt > 0) != 0ull) {
+      if (__ballot(cnt > INS_MAX) != 0ull) fold_sort();
+      else insert_all();
+    }
+    const int nb = next_block();
+    cur = active ? nb : -1;
+  }
+  if (qvalid && p < K) {
+    idx[((size_t)b * s + q) * K + p] = (int)bl;
+    if (dist) dist[((size_t)b * s + q) * K + p] = __uint_as_float(bh);
+  }
+}
+
 }  // namespace pwclo
 
 static int knn_slabs(int n) {            // ~ sqrt(#blocks), power of two in [2,16]
@@ -582,6 +794,23 @@ extern "C" void knn_point_ws_kernel_wrapper(int b, int n, int s, int nsample, co
   else if (regs <= 8) { KB_CASE(8) }
   else { KB_CASE(16) }
 #undef KB_CASE
+  // K <= 32: several queries per wave (knn_rows_kernel); PWCLO_KNN_ROWS=0 keeps one query per wave (A/B switch)
+  static int use_rows = -1;
+  if (use_rows < 0) { const char *e = getenv("PWCLO_KNN_ROWS"); use_rows = e ? atoi(e) : 1; }
+  const int L = nsample <= 16 ? 16 : 32;
+  const int need = ceil_div(nblk, L);
+#define KR_CASE(LL, RR)                                                                                        \
+  if (L == LL && need <= RR) {                                                                                 \
+    hipLaunchKernelGGL((knn_rows_kernel<LL, RR>), dim3(ceil_div(s, KNN_WAVES * (64 / LL)), b), dim3(KNN_WAVES * 64), \
+                       0, current_stream(), nblk, s, nsample, rows, boxes, new_xyz, idx, dist);                \
+    check_launch("knn_point(rows)");                                                                           \
+    return;                                                                                                    \
+  }
+  if (use_rows && nsample <= 32) {
+    KR_CASE(16, 2) KR_CASE(16, 3) KR_CASE(16, 5) KR_CASE(16, 9) KR_CASE(16, 17)
+    KR_CASE(32, 1) KR_CASE(32, 2) KR_CASE(32, 3) KR_CASE(32, 5) KR_CASE(32, 9)
+  }
+#undef KR_CASE
   hipLaunchKernelGGL(knn_pruned_kernel, dim3(ceil_div(s, KNN_WAVES), b), dim3(KNN_WAVES * 64), 0,
                      current_stream(), nblk, s, nsample, rows, boxes, new_xyz, idx, dist);
   check_launch("knn_point(pruned)");

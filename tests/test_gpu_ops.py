@@ -334,6 +334,25 @@ def test_knn_pruned_equals_exhaustive(cuda, k, n, s):
     assert torch.equal(d1, d0)
 
 
+@pytest.mark.parametrize("k,n,s", [(4, 2000, 523), (6, 2000, 523), (16, 5000, 1201), (32, 5000, 1201), (8, 16384, 600),
+                                   (32, 16000, 513), (1, 600, 700), (12, 513, 512)])
+def test_knn_rows_kernel_ties_and_ragged_shapes(cuda, k, n, s):
+    """K <= 32 with >= 512 queries runs several queries per wave (csrc/knn.hip: knn_rows_kernel, L = 16 / 32 lanes per
+    query): integer-lattice clouds (exact distance ties at every rank, duplicated points: lower index first), query
+    counts that are not a multiple of the queries per wave / workgroup, every block-register case (n up to 16384),
+    against the oracle -- indices AND keys bit for bit."""
+    gen = torch.Generator().manual_seed(k * 100 + n)
+    xyz = torch.randint(-7, 8, (2, n, 3), generator=gen).float()
+    xyz[1] = (torch.rand(n, 3, generator=gen) * 2 - 1) * 25            # one lattice cloud, one random cloud
+    xyz[1, 100:140] = xyz[1, 60:100]                                  # + exact duplicates
+    new_xyz = torch.stack((xyz[0, torch.randperm(n, generator=gen)[:s] % n] if s <= n else xyz[0, torch.randint(0, n, (s,), generator=gen)],
+                           (torch.rand(s, 3, generator=gen) * 2 - 1) * 25)).contiguous()
+    d_ref, i_ref = O.knn_point_with_dist(k, xyz, new_xyz)
+    d, i = E.knn_point(k, g(xyz, cuda), g(new_xyz, cuda), return_dist=True)
+    assert torch.equal(i.cpu(), i_ref)
+    assert torch.equal(d.cpu(), d_ref)
+
+
 def test_kitti_transform_filter_and_sampling(cuda):
     """the on-device transform + filter equals the NumPy restatement of the dataset code
     (fp64 arithmetic, coordinates rounded to fp32: identical up to one fp32 ulp of BLAS-vs-fma ordering;
