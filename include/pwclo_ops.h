@@ -129,9 +129,9 @@ void knn_point_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz
                               const float *new_xyz, int *idx, float *dist);
 
 /* Same result through an exact spatially pruned search (Morton-sorted candidate blocks with
- * bounding boxes) when 512 <= n <= 16384: needs a caller-provided device workspace of
+ * bounding boxes) when 256 <= n <= 16384: needs a caller-provided device workspace of
  * knn_point_workspace_bytes(b, n) bytes (0 = not applicable: the exhaustive kernel is used and
- * `workspace` may be NULL; also used when s < 512, where the build does not amortise).
+ * `workspace` may be NULL; also used when s < 256, where the build does not amortise).
  * Bit-identical output to knn_point_kernel_wrapper. */
 long long knn_point_workspace_bytes(int b, int n);
 void knn_point_ws_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz,

@@ -240,7 +240,7 @@ extern "C" void knn_point_kernel_wrapper(int b, int n, int s, int nsample, const
 }
 
 // =====================================================================================================
-// Spatially pruned exact search (n >= 512).
+// Spatially pruned exact search (n >= 256, PWCLO_KNN_MIN_N).
 //
 // knn_build_kernel (one workgroup per cloud): counting sort into (x-slab, z-bin) order, rows
 // (x, y, z, bits(original index)) in that order + one axis-aligned box per block of 64 consecutive rows.
@@ -763,8 +763,15 @@ static int knn_slabs(int n) {            // ~ sqrt(#blocks), power of two in [2,
   return nslab;
 }
 
+static int knn_tune(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static int knn_min_n() { static const int v = knn_tune("PWCLO_KNN_MIN_N", 256); return v; }
+static int knn_min_s() { static const int v = knn_tune("PWCLO_KNN_MIN_S", 256); return v; }
+
 extern "C" long long knn_point_workspace_bytes(int b, int n) {
-  if (n < 512 || n > pwclo::KNN_MAX_SORT) return 0;       // exhaustive kernel: no workspace
+  if (n < knn_min_n() || n > pwclo::KNN_MAX_SORT) return 0;       // exhaustive kernel: no workspace
   const long long nblk = (n + 63) / 64 + knn_slabs(n);
   return (long long)b * nblk * (64 * 16 + 32);
 }
@@ -773,7 +780,7 @@ extern "C" void knn_point_ws_kernel_wrapper(int b, int n, int s, int nsample, co
                                             const float *new_xyz, int *idx, float *dist,
                                             void *workspace) {
   if (b <= 0 || s <= 0) return;
-  if (workspace == nullptr || knn_point_workspace_bytes(b, n) == 0 || s < 512) {
+  if (workspace == nullptr || knn_point_workspace_bytes(b, n) == 0 || s < knn_min_s()) {
     knn_point_kernel_wrapper(b, n, s, nsample, xyz, new_xyz, idx, dist);   // too few queries to amortise the build
     return;
   }

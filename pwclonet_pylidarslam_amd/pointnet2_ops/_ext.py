@@ -160,6 +160,10 @@ def scatter_grad_deterministic(grad_out, idx, n):
 
 # ---- native replacements of pure-PyTorch ops (include/pwclo_ops.h section 2) ---------------------
 
+import os as _os
+_KNN_MIN_S = int(_os.environ.get("PWCLO_KNN_MIN_S", "256"))     # fewer queries: the exhaustive kernel (no build pass)
+
+
 def knn_point(nsample, xyz, new_xyz, return_dist=False, exhaustive=None):
     """Native kernel behind ``pytorch_utils.knn_point``.  xyz (B,N,3), new_xyz (B,S,3) ->
     idx (B,S,nsample) i32 ascending by distance (ties: lower index); optionally the keys."""
@@ -168,7 +172,7 @@ def knn_point(nsample, xyz, new_xyz, return_dist=False, exhaustive=None):
     S = new_xyz.shape[1]
     idx = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
     dist = torch.empty((B, S, nsample), dtype=torch.float32, device=xyz.device) if return_dist else None
-    ws_bytes = _lib.load().knn_point_workspace_bytes(B, N) if (exhaustive is not True and (S >= 512 or exhaustive is False)) else 0
+    ws_bytes = _lib.load().knn_point_workspace_bytes(B, N) if (exhaustive is not True and (S >= _KNN_MIN_S or exhaustive is False)) else 0
     if ws_bytes > 0:    # exact spatially pruned search (same output), needs scratch for the sorted rows
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=xyz.device)
         _lib.call("knn_point_ws_kernel_wrapper", xyz.device, B, N, S, int(nsample), _p(xyz), _p(new_xyz),
