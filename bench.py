@@ -233,12 +233,11 @@ def bf16x3_variant(args, dev, x1, x2, pose_ref, streams):
     the bf16 matrix pipe, fp32 accumulate), measured AFTER the headline region on the same
     inputs and weights.  Reported beside the headline number, never as it."""
     from pwclonet_pylidarslam_amd.graphed import PipelinedForward
-    os.environ["PWCLO_BF16X3"] = "1"
     try:
         torch.manual_seed(1234)
         net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(dev), scalar_last=False,
                             log_mode=args.log_mode)).to(dev).eval()
-        net.prepare_fused()
+        net.prepare_fused(dtype="bf16x3")
         pipe = PipelinedForward(net, depth=args.inflight, streams=streams)
         pipe.prepare(x1, x2)
         for _ in range(args.warmup):
@@ -250,7 +249,7 @@ def bf16x3_variant(args, dev, x1, x2, pose_ref, streams):
         dist_util.fence(dev)
         dt = time.perf_counter() - t0
     finally:
-        os.environ["PWCLO_BF16X3"] = "0"
+        pass
     return {"value": args.batch * args.steps / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt / args.steps,
             "max_abs_pose_diff_vs_headline": float((pose - pose_ref).abs().max()),
             "note": "opt-in PWCLO_BF16X3=1; not the headline path.  The pose difference is dominated by one pair whose "
@@ -271,6 +270,152 @@ def step_roofline(fam, ms_per_step):
             "note": "frac = all MFMA-stack FLOP of a step / the WHOLE pipelined step time (FPS, knn and glue "
                     "included) / fp32 MFMA peak; mlp_family_frac = the same FLOP / serial sum of the stack "
                     "kernels' isolated launch times"}
+
+
+BF16_MFMA_PEAK_TFLOPS = 2516.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def raw_frames(seed, b, n, device):
+    """KITTI-360-sized raw sensor frames (b, n, 4) = x, y, z, intensity in the sensor frame: lidar-like radial
+    density, z from below the wheel axis (ground, filtered out) to above it."""
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.randn(b, n, 2, generator=g) * 18.0
+    z = torch.rand(b, n, 1, generator=g) * 5.0 - 2.0
+    inten = torch.rand(b, n, 1, generator=g)
+    return torch.cat((xy, z, inten), dim=2).contiguous().to(device)
+
+
+def config5_cpu_baseline(sd, f1, f2, npoints, near, threads):
+    """The oracle's version of one configs[4] step on a bounded sample (2 pairs): NumPy KITTI-360 filter
+    (oracle/preprocess.py), C furthest point sampling of the ~95k survivors to `npoints` (OpenMP over the clouds),
+    oracle.model forward in fp32."""
+    from oracle import model as omodel, ops as oops, preprocess as opre
+    cores = threads or oops.usable_host_cores()
+    torch.set_num_threads(cores)
+    oops.set_num_threads(cores)
+    pairs = f1.shape[0]
+    t0 = time.perf_counter()
+    clouds = []
+    for fr in list(f1) + list(f2):
+        pts, keep = opre.kitti360_filter(fr.numpy(), near)
+        clouds.append(torch.from_numpy(np.ascontiguousarray(pts[keep])))
+    t_filter = time.perf_counter() - t0
+    cap = max(c.shape[0] for c in clouds)
+    packed = torch.zeros((len(clouds), cap, 3))
+    for i, c in enumerate(clouds):
+        packed[i, :c.shape[0]] = c
+    idx = oops.furthest_point_sampling(packed, npoints)
+    sampled = torch.gather(packed, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    t_fps = time.perf_counter() - t0 - t_filter
+    x1 = sampled[:pairs].permute(0, 2, 1).contiguous()
+    x2 = sampled[pairs:].permute(0, 2, 1).contiguous()
+    omodel.pwclonet_forward(sd, x1, x2)
+    dt = time.perf_counter() - t0
+    return {"value": pairs / dt, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            "stages_s": {"filter": t_filter, "fps_to_%d" % npoints: t_fps, "pyramid_fp32": dt - t_filter - t_fps},
+            "sample": "%d pairs of raw %d-row frames: NumPy KITTI-360 filter, C oracle FPS of the survivors (max %d) to %d "
+                      "on %d OpenMP threads, oracle.model forward (fp32, torch CPU) -- %.1f s of CPU work"
+                      % (pairs, f1.shape[1], cap, npoints, cores, dt)}
+
+
+def run_config5(args):
+    """BASELINE.json configs[4]: a batch of 8 raw KITTI-360-sized frame pairs (2 x ~120k rows of x,y,z,intensity,
+    resident in HBM) -> on-device ground / range filter + compaction -> furthest point sampling of the ~95k survivors
+    to 8192 (cooperative multi-workgroup sampler, exact) -> full pyramid with dtype="bf16" stack layers -> poses.
+    A step = all of that for one batch; launches are eager (the cooperative launch cannot be graph-captured and the
+    24 ms sampler dwarfs launch gaps).  One JSON line like the headline's."""
+    from pwclonet_pylidarslam_amd import preprocess
+    rank, local_rank, world = dist_util.env_world()
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist_util.init("nccl", dev)
+    _lib.load()
+    B, rows, npts, near = args.batch, args.rows, args.npoints, 35.0
+    torch.manual_seed(1234)
+    net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(dev), scalar_last=False,
+                        log_mode="none")).to(dev).eval()
+    net.prepare_fused(dtype=args.dtype)
+    f1, f2 = raw_frames(1 + 10 * rank, B, rows, dev), raw_frames(2 + 10 * rank, B, rows, dev)
+    frames = torch.cat((f1, f2), dim=0)
+
+    def step():
+        clouds, counts = preprocess.frames_to_clouds(frames, npts, dataset="kitti360", near_threshold=near)
+        x1 = clouds[:B].transpose(1, 2).contiguous()
+        x2 = clouds[B:].transpose(1, 2).contiguous()
+        with torch.no_grad():
+            pose, _ = net(x1, None, x2, None)
+        return pose, counts
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    times = []
+    for _ in range(max(3, args.repeats)):
+        dist_util.fence(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pose, counts = step()
+        dist_util.fence(dev)
+        times.append(dist_util.max_over_ranks(time.perf_counter() - t0, dev))
+    _lib.synchronize(dev)                       # raises if the cooperative sampler reported a timeout
+    assert torch.isfinite(pose).all()
+    ordered = sorted(times)
+    dt = ordered[len(ordered) // 2]
+    if rank != 0:
+        dist_util.finish()
+        return
+    # per-stage times (HIP events on the launch stream) and the per-launch profile of one more step
+    def ev_time(fn, reps=2):
+        fn(); torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            out = fn()
+        b.record(); torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / reps, out
+    t_filter, (xyz, keep) = ev_time(lambda: preprocess.kitti360_filter(frames, near))
+    t_compact, (packed, cnts) = ev_time(lambda: preprocess.compact(xyz, keep))
+    from pwclonet_pylidarslam_amd.pointnet2_ops import _ext
+    t_fps, idx = ev_time(lambda: _ext.furthest_point_sampling(packed, npts))
+    clouds = torch.gather(packed, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    x1, x2 = clouds[:B].transpose(1, 2).contiguous(), clouds[B:].transpose(1, 2).contiguous()
+    fam = instrumented_pass(net, x1, x2, passes=2)
+    mlp = fam.get("mlp", {"ms": 0.0, "flops": 0.0})
+    t_pyr = sum(d["ms"] for d in fam.values())
+    n_surv = int(cnts.max())
+    fps_bytes = 2 * B * (12.0 * n_surv + 16.0 * npts)
+    out = {
+        "metric": "PWCLO-Net forward frame-pairs/sec, raw ~120k-pt KITTI-360 frames -> 8192-pt FPS -> pyramid, batch 8",
+        "value": world * B * args.steps / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": max(1, args.warmup), "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "repeats": {"n": len(times), "reported": "median", "ms_per_step_all": [1e3 * t / args.steps for t in times]},
+        "config": {"workload": "BASELINE.json configs[4]: %d pairs x 2 x %d raw rows (x,y,z,i) per GPU, KITTI-360 filter "
+                               "(survivors up to %d per frame), exact furthest point sampling to %d, full 4-level pyramid; "
+                               "stack layers in %s (fp32 accumulate), coordinates / distances / indices fp32"
+                               % (B, rows, n_surv, npts, args.dtype),
+                   "global_batch": world * B, "npoints": npts, "parallelism": "replicas x%d" % world,
+                   "launch": "eager (cooperative launch of the large-cloud sampler)"},
+        "stages_ms": {"kitti360_filter": t_filter, "compaction": t_compact, "fps_%d_to_%d" % (n_surv, npts): t_fps,
+                      "pyramid_kernels_%s" % args.dtype: t_pyr},
+        "roofline": {"kernel": "fps_coop_kernel<16>", "bound": "hbm",
+                     "achieved": fps_bytes / 1e9 / (t_fps / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": fps_bytes / 1e9 / (t_fps / 1e3) / HBM_PEAK_GBS, "traffic": None,
+                     "share_of_step": t_fps / (1e3 * dt / args.steps),
+                     "ns_per_iteration": 1e6 * t_fps / (npts - 1),
+                     "note": "the dominant kernel is a chain of %d dependent arg-max iterations shared by 8 workgroups per "
+                             "cloud: latency-bound (cross-workgroup exchange + distance update), its %d MB of algorithmic "
+                             "HBM bytes are irrelevant; reported against the HBM roof because the contract asks for one"
+                             % (npts - 1, int(fps_bytes / 1e6)),
+                     "mlp_family": {"dtype": args.dtype, "ms_per_step": mlp["ms"],
+                                    "algorithmic_gflop_per_step": mlp["flops"] / 1e9,
+                                    "achieved_tflops": mlp["flops"] / 1e9 / mlp["ms"] if mlp["ms"] else 0.0,
+                                    "peak_tflops": BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS,
+                                    "note": "batch 8: every stack launch is launch / fill bound (<= 16 clouds)"}}}
+    if not args.no_cpu_baseline and world == 1:
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        out["cpu_baseline"] = config5_cpu_baseline(sd, f1[:2].cpu(), f2[:2].cpu(), npts, near, args.cpu_threads)
+    print(json.dumps(out), flush=True)
+    dist_util.finish()
 
 
 def dry_run(args):
@@ -295,13 +440,13 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=None, help="default 40 (--config 5: 5)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=0,
                     help="how many times the K-step timed region is run back to back (median reported); 0 = as many "
                          "as fit in about --timed-seconds (at least 5, at most 200), decided from the first repeat")
     ap.add_argument("--timed-seconds", type=float, default=3.0)
-    ap.add_argument("--batch", type=int, default=32, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frame pairs per GPU per step: default 32 (--config 5: 8)")
     ap.add_argument("--npoints", type=int, default=8192)
     ap.add_argument("--log-mode", default="host", choices=["host", "device", "none"],
                     help="host = the reference's log_dict on the host (lazy: built when read)")
@@ -323,10 +468,20 @@ def main():
                     help="host threads of the CPU baseline (0 = the cgroup CPU quota / affinity of this process)")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra (untimed-region) measurement of the opt-in bf16x3 split path")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 5],
+                    help="3 = the headline workload (BASELINE.json configs[2]: B=32 2x8192 fp32); 5 = configs[4]: raw "
+                         "~120k-row frames -> FPS to 8192 -> pyramid in bf16, batch 8")
+    ap.add_argument("--rows", type=int, default=120000, help="--config 5: raw rows per frame")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "bf16x3"],
+                    help="stack-layer format of the fused kernels (default: f32 for the headline, bf16 for --config 5)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing only: rendezvous + fences + aggregation over gloo with a host sleep as the step")
     args = ap.parse_args()
 
+    if args.steps is None:
+        args.steps = 5 if args.config == 5 else 40
+    if args.batch is None:
+        args.batch = 8 if args.config == 5 else 32
     if args.gpus > 1 and not dist_util.launched_by_torchrun():
         # The driver's `python bench.py --gpus N`: this process has made no GPU call and makes none; it starts
         # N rank processes (one per GPU) and passes their exit code on.
@@ -342,6 +497,11 @@ def main():
         sys.exit(2)
     if args.dry_run:
         return dry_run(args)
+    if args.config == 5:
+        args.dtype = args.dtype or "bf16"
+        if args.repeats <= 0:
+            args.repeats = 3
+        return run_config5(args)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist_util.init("nccl", dev)
@@ -351,7 +511,7 @@ def main():
     net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(dev), scalar_last=False,
                         log_mode=args.log_mode)).to(dev).eval()
     if not args.unfused:
-        net.prepare_fused()
+        net.prepare_fused(dtype=args.dtype)
     x1, x2 = make_batch(args.batch, args.npoints, 1000 + rank, dev)
 
     pipe = None
@@ -402,7 +562,7 @@ def main():
             "value": world * args.batch * args.steps / dt, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype or "f32", "data": "synthetic",
             "repeats": {"n": len(times), "reported": "median",
                         "ms_per_step_min": 1e3 * ordered[0] / args.steps,
                         "ms_per_step_median": 1e3 * dt / args.steps,
@@ -427,7 +587,8 @@ def main():
             out["roofline"] = roof
             out["kernels"] = kernels
         if not args.no_variants and world == 1 and pipe is not None and not args.unfused \
-                and args.pipeline == "whole" and os.environ.get("PWCLO_BF16X3", "0") == "0":
+                and args.pipeline == "whole" and (args.dtype or "f32") == "f32" \
+                and os.environ.get("PWCLO_BF16X3", "0") == "0":
             out["variants"] = {"bf16x3": bf16x3_variant(args, dev, x1, x2, pose.clone(), pipe.streams)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(net, args.npoints, args.cpu_forwards, args.cpu_threads)

@@ -211,7 +211,8 @@ void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int c2, int w1
  *     to a1 and a2: k rounded up to 8/16/32, or 6 for k == 6 (dense layout of the refinement levels).
  *     xyz1 (b,s,3), feat1 (b,s,c), xyz2 (b,n,3), feat2 (b,n,c), idx (b,s,k).
  * Packed-weight format (entry points that take `wfmt, packed_floats`): 0 = fp32 operand tiles
- *     (v_mfma_f32_16x16x4_f32), 1 = the opt-in three-term bf16 split tiles (csrc/mlp_core.hpp); the format is a
+ *     (v_mfma_f32_16x16x4_f32), 1 = the opt-in three-term bf16 split tiles, 2 = bf16 tiles (dtype "bf16":
+ *     v_mfma_f32_16x16x32_bf16 on operands rounded once, fp32 accumulate; csrc/mlp_core.hpp); the format is a
  *     property of the buffer, fixed when it was packed.  packed_floats = its length; a length that does not match
  *     the layout the selected kernel indexes is refused with PWCLO_EINVAL (never read out of bounds).
  * a2: mlp_conv_xyz_1(geometry10), mlp2_convs, softmax over k, sum_k w*pix -> out (b,s,64).

@@ -116,10 +116,10 @@ struct SAHArgs {
   int B, N, S, K;
 };
 
-template <int B1, int B2, int B3, int KP, int P, int W, bool XYZ_ONLY, bool BF3 = false>
+template <int B1, int B2, int B3, int KP, int P, int W, bool XYZ_ONLY, int FMT = 0>
 __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
   TraceScope trace_scope_(TK_SA_H);
-  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<BF3>(B1, B2), W3 = layer_floats_any<BF3>(B2, B3);
+  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<FMT>(B1, B2), W3 = layer_floats_any<FMT>(B2, B3);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2 + W3);
   __syncthreads();
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
         for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
       mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
     }
-    mlp_layer_any<BF3, B1, B2, P, true>(h2, h1, lds_w + W1, lane);
-    mlp_layer_any<BF3, B2, B3, P, false>(h3, h2, lds_w + W1 + W2, lane);   // its ReLU is applied after the pool
+    mlp_layer_any<FMT, B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    mlp_layer_any<FMT, B2, B3, P, false>(h3, h2, lds_w + W1 + W2, lane);   // its ReLU is applied after the pool
     constexpr int GROUP = KP < 16 ? KP : 16;
     constexpr int BPQ = KP > 16 ? KP / 16 : 1;
 #pragma unroll
@@ -193,11 +193,11 @@ struct UpHArgs {
   int B, N, S, K;
 };
 
-template <int KP, int P, int W, bool BF3 = false>
+template <int KP, int P, int W, int FMT = 0>
 __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
   TraceScope trace_scope_(TK_UPCONV_H);
   constexpr int B1 = 8, B2 = 4;
-  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<BF3>(B1, B2);
+  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<FMT>(B1, B2);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2);
   __syncthreads();
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
     mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
-    mlp_layer_any<BF3, B1, B2, P, false>(h2, h1, lds_w + W1, lane);   // its ReLU is applied after the pool
+    mlp_layer_any<FMT, B1, B2, P, false>(h2, h1, lds_w + W1, lane);   // its ReLU is applied after the pool
     constexpr int GROUP = KP < 16 ? KP : 16;
 #pragma unroll
     for (int o = 0; o < B2; ++o)
@@ -318,11 +318,11 @@ struct CVHArgs {
   int B, N, S, K;
 };
 
-template <int KP, int P, int W, bool BF3 = false>
+template <int KP, int P, int W, int FMT = 0>
 __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
   TraceScope trace_scope_(TK_CV_A1_H);
   constexpr int B1 = 8, B2 = 4, B3 = 4;
-  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<BF3>(B1, B2), W3 = layer_floats_any<BF3>(B2, B3);
+  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<FMT>(B1, B2), W3 = layer_floats_any<FMT>(B2, B3);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2 + W3);
   __syncthreads();
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) h1[o][p] = ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o);
     mlp_layer_init<1, B1, P, true, 3>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // geometry(10)
-    mlp_layer_any<BF3, B1, B2, P, true>(h2, h1, lds_w + W1, lane);
-    mlp_layer_any<BF3, B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
+    mlp_layer_any<FMT, B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+    mlp_layer_any<FMT, B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
 #pragma unroll
     for (int o = 0; o < B3; ++o)
 #pragma unroll
@@ -368,10 +368,10 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
   }
 }
 
-template <int KP, int P, int W, bool BF3 = false>
+template <int KP, int P, int W, int FMT = 0>
 __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
   TraceScope trace_scope_(TK_CV_B_H);
-  constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<BF3>(4, 8), W2 = layer_floats_any<BF3>(8, 4);
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<FMT>(4, 8), W2 = layer_floats_any<FMT>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, WX + W1 + W2);
   __syncthreads();
@@ -408,11 +408,8 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) h1[o][p] = ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o);
     mlp_layer<1, 4, P, true, 3>(enc, geo, lds_w, lane);
-    if constexpr (BF3)
-      mlp_layer_bf3_init<4, 8, P, true>(h1, enc, lds_w + WX, lane, [&](int o, int p) { return h1[o][p]; });
-    else
-      mlp_layer_init<4, 8, P, true>(h1, enc, lds_w + WX, lane, [&](int o, int p) { return h1[o][p]; });
-    mlp_layer_any<BF3, 8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+    mlp_layer_any_init<FMT, 4, 8, P, true>(h1, enc, lds_w + WX, lane, [&](int o, int p) { return h1[o][p]; });
+    mlp_layer_any<FMT, 8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
     // softmax over the neighbours, weighted sum of the gathered first-aggregate rows
     constexpr int GROUP = KP < 16 ? KP : 16;
     const float NEG_INF = __int_as_float(0xff800000);
@@ -496,11 +493,17 @@ extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, in
     static bool attr = false, attr3 = false;                                                          \
     constexpr int lds = 4 * (layer_floats(1, A1 / 16) + layer_floats(A1 / 16, A2 / 16) +               \
                              layer_floats(A2 / 16, A3 / 16));                                          \
-    constexpr int lds3 = 4 * (layer_floats(1, A1 / 16) + layer_floats_any<true>(A1 / 16, A2 / 16) +    \
-                              layer_floats_any<true>(A2 / 16, A3 / 16));                               \
-    PWCLO_REQUIRE_PACKED("sa_fused_h", wfmt, packed_floats, lds / 4, lds3 / 4);                        \
+    constexpr int lds3 = 4 * (layer_floats(1, A1 / 16) + layer_floats_any<1>(A1 / 16, A2 / 16) +       \
+                              layer_floats_any<1>(A2 / 16, A3 / 16));                                  \
+    constexpr int lds2 = 4 * (layer_floats(1, A1 / 16) + layer_floats_any<2>(A1 / 16, A2 / 16) +       \
+                              layer_floats_any<2>(A2 / 16, A3 / 16));                                  \
+    static bool attr2 = false;                                                                        \
+    PWCLO_REQUIRE_PACKED("sa_fused_h", wfmt, packed_floats, lds / 4, lds3 / 4, lds2 / 4);              \
     if (wfmt == PWCLO_WFMT_BF16X3)                                                                    \
-      launch_h<WW>(sa_h_kernel<A1 / 16, A2 / 16, A3 / 16, KP, PP, WW, XYZ, true>, attr3, lds3,          \
+      launch_h<WW>(sa_h_kernel<A1 / 16, A2 / 16, A3 / 16, KP, PP, WW, XYZ, 1>, attr3, lds3,             \
+                   tiles_h(b, s, KP, PP), a);                                                         \
+    else if (wfmt == PWCLO_WFMT_BF16)                                                                 \
+      launch_h<WW>(sa_h_kernel<A1 / 16, A2 / 16, A3 / 16, KP, PP, WW, XYZ, 2>, attr2, lds2,             \
                    tiles_h(b, s, KP, PP), a);                                                         \
     else                                                                                              \
       launch_h<WW>(sa_h_kernel<A1 / 16, A2 / 16, A3 / 16, KP, PP, WW, XYZ>, attr, lds, tiles_h(b, s, KP, PP), a); \
@@ -531,8 +534,11 @@ extern "C" void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const 
   static const int lane_up = fh_tuning("PWCLO_LANE_UP", 1);
   static bool attrl = false;
   const long long t16 = (long long)b * ((s + 15) / 16);
-  PWCLO_REQUIRE_PACKED("upconv_fused_h", wfmt, packed_floats, lds / 4, lds3 / 4);
-  if (wfmt == PWCLO_WFMT_BF16X3) launch_h<16>(upconv_h_kernel<8, 1, 16, true>, attr3, lds3, tiles_h(b, s, 8, 1), a);
+  constexpr int lds2 = 4 * (layer_floats(1, 8) + layer_floats_bf16(8, 4));
+  static bool attr2 = false;
+  PWCLO_REQUIRE_PACKED("upconv_fused_h", wfmt, packed_floats, lds / 4, lds3 / 4, lds2 / 4);
+  if (wfmt == PWCLO_WFMT_BF16X3) launch_h<16>(upconv_h_kernel<8, 1, 16, 1>, attr3, lds3, tiles_h(b, s, 8, 1), a);
+  else if (wfmt == PWCLO_WFMT_BF16) launch_h<16>(upconv_h_kernel<8, 1, 16, 2>, attr2, lds2, tiles_h(b, s, 8, 1), a);
   else if (lane_up && t16 > 2048) launch_h<16>(upconv_lane_kernel<16>, attrl, lds, t16, a);   // in-lane max over K
   else launch_h<16>(upconv_h_kernel<8, 1, 16>, attr, lds, tiles_h(b, s, 8, 1), a);
   check_launch("upconv_fused_h");
@@ -551,12 +557,22 @@ extern "C" void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const f
   constexpr int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4) + layer_floats(4, 4));
   constexpr int lds3 = 4 * (layer_floats(1, 8) + layer_floats_bf3(8, 4) + layer_floats_bf3(4, 4));
   static bool a32 = false, a16 = false, a8 = false, a6 = false, b32 = false, b16 = false, b8 = false, b6 = false;
-  PWCLO_REQUIRE_PACKED("cv_fused_a1_h", wfmt, packed_floats, lds / 4, lds3 / 4);
+  constexpr int lds2 = 4 * (layer_floats(1, 8) + layer_floats_bf16(8, 4) + layer_floats_bf16(4, 4));
+  PWCLO_REQUIRE_PACKED("cv_fused_a1_h", wfmt, packed_floats, lds / 4, lds3 / 4, lds2 / 4);
   if (wfmt == PWCLO_WFMT_BF16X3) {
-    if (kp == 6) launch_h<16>(cv_a1_h_kernel<6, 1, 16, true>, b6, lds3, tiles_h(b, s, 6, 1), a);
-    else if (kp == 32) launch_h<16>(cv_a1_h_kernel<32, 1, 16, true>, b32, lds3, tiles_h(b, s, 32, 1), a);
-    else if (kp == 16) launch_h<16>(cv_a1_h_kernel<16, 1, 16, true>, b16, lds3, tiles_h(b, s, 16, 1), a);
-    else launch_h<16>(cv_a1_h_kernel<8, 1, 16, true>, b8, lds3, tiles_h(b, s, 8, 1), a);
+    if (kp == 6) launch_h<16>(cv_a1_h_kernel<6, 1, 16, 1>, b6, lds3, tiles_h(b, s, 6, 1), a);
+    else if (kp == 32) launch_h<16>(cv_a1_h_kernel<32, 1, 16, 1>, b32, lds3, tiles_h(b, s, 32, 1), a);
+    else if (kp == 16) launch_h<16>(cv_a1_h_kernel<16, 1, 16, 1>, b16, lds3, tiles_h(b, s, 16, 1), a);
+    else launch_h<16>(cv_a1_h_kernel<8, 1, 16, 1>, b8, lds3, tiles_h(b, s, 8, 1), a);
+    check_launch("cv_fused_a1_h");
+    return;
+  }
+  if (wfmt == PWCLO_WFMT_BF16) {
+    static bool c32 = false, c16 = false, c8 = false, c6 = false;
+    if (kp == 6) launch_h<16>(cv_a1_h_kernel<6, 1, 16, 2>, c6, lds2, tiles_h(b, s, 6, 1), a);
+    else if (kp == 32) launch_h<16>(cv_a1_h_kernel<32, 1, 16, 2>, c32, lds2, tiles_h(b, s, 32, 1), a);
+    else if (kp == 16) launch_h<16>(cv_a1_h_kernel<16, 1, 16, 2>, c16, lds2, tiles_h(b, s, 16, 1), a);
+    else launch_h<16>(cv_a1_h_kernel<8, 1, 16, 2>, c8, lds2, tiles_h(b, s, 8, 1), a);
     check_launch("cv_fused_a1_h");
     return;
   }
@@ -580,9 +596,13 @@ extern "C" void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xy
   constexpr int lds3 = 4 * (layer_floats(1, 4) + layer_floats_bf3(4, 8) + layer_floats_bf3(8, 4));
   static const int coarse_w4 = fh_tuning("PWCLO_COARSE_W4", 1);
   const bool small = coarse_w4 && tiles_h(b, s, 4, 1) <= 2048;
-  PWCLO_REQUIRE_PACKED("cv_fused_b_h", wfmt, packed_floats, lds / 4, lds3 / 4);
-  if (wfmt == PWCLO_WFMT_BF16X3 && small) launch_h<4>(cv_b_h_kernel<4, 1, 4, true>, attr3_s, lds3, tiles_h(b, s, 4, 1), a);
-  else if (wfmt == PWCLO_WFMT_BF16X3) launch_h<16>(cv_b_h_kernel<4, 1, 16, true>, attr3, lds3, tiles_h(b, s, 4, 1), a);
+  constexpr int lds2 = 4 * (layer_floats(1, 4) + layer_floats_bf16(4, 8) + layer_floats_bf16(8, 4));
+  static bool attr2 = false, attr2_s = false;
+  PWCLO_REQUIRE_PACKED("cv_fused_b_h", wfmt, packed_floats, lds / 4, lds3 / 4, lds2 / 4);
+  if (wfmt == PWCLO_WFMT_BF16X3 && small) launch_h<4>(cv_b_h_kernel<4, 1, 4, 1>, attr3_s, lds3, tiles_h(b, s, 4, 1), a);
+  else if (wfmt == PWCLO_WFMT_BF16X3) launch_h<16>(cv_b_h_kernel<4, 1, 16, 1>, attr3, lds3, tiles_h(b, s, 4, 1), a);
+  else if (wfmt == PWCLO_WFMT_BF16 && small) launch_h<4>(cv_b_h_kernel<4, 1, 4, 2>, attr2_s, lds2, tiles_h(b, s, 4, 1), a);
+  else if (wfmt == PWCLO_WFMT_BF16) launch_h<16>(cv_b_h_kernel<4, 1, 16, 2>, attr2, lds2, tiles_h(b, s, 4, 1), a);
   else if (small) launch_h<4>(cv_b_h_kernel<4, 1, 4>, attr_s, lds, tiles_h(b, s, 4, 1), a);
   else launch_h<16>(cv_b_h_kernel<4, 1, 16>, attr, lds, tiles_h(b, s, 4, 1), a);
   check_launch("cv_fused_b_h");

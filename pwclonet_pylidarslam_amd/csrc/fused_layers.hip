@@ -266,10 +266,10 @@ __global__ __launch_bounds__(W * 64) void cv_a1_kernel(CVArgs a) {
 }
 
 // a2: enc = mlp_conv_xyz_1(geo); w = softmax_k(mlp2_convs([enc | feat])); out = sum_k w * feat.
-template <int KP, int P, int W, bool BF3 = false>
+template <int KP, int P, int W, int FMT = 0>
 __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
   TraceScope trace_scope_(TK_CV_A2);
-  constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<BF3>(8, 8), W2 = layer_floats_any<BF3>(8, 4);
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<FMT>(8, 8), W2 = layer_floats_any<FMT>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, WX + W1 + W2);
   __syncthreads();
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) cat[m][p] = enc[m][p];
     f32x4 h1[8][P], h2[4][P];
-    mlp_layer_any<BF3, 8, 8, P, true>(h1, cat, lds_w + WX, lane);
-    mlp_layer_any<BF3, 8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
+    mlp_layer_any<FMT, 8, 8, P, true>(h1, cat, lds_w + WX, lane);
+    mlp_layer_any<FMT, 8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
     constexpr int GROUP = KP < 16 ? KP : 16;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
@@ -330,11 +330,11 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
 //   i >= 6: query 6 + h,  neighbour 2p + (i-6) -- "split" segment, lanes 6,7 / 14,15 of the three
 //           blocks: reduced in-lane across the blocks, then across the lane pair (one DPP step).
 // cv_a1 writes the per-pixel features densely as (B, S, 6, 64) for this kernel.
-template <int W, bool BF3 = false>
+template <int W, int FMT = 0>
 __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
   TraceScope trace_scope_(TK_CV_A2_DENSE6);
   constexpr int P = 3;
-  constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<BF3>(8, 8), W2 = layer_floats_any<BF3>(8, 4);
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<FMT>(8, 8), W2 = layer_floats_any<FMT>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, WX + W1 + W2);
   __syncthreads();
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
       load_row_blocks<4>(&cat[4][p], P, at32(a.pix, slot << 8), g);
     }
     f32x4 h2[4][P];
-    if constexpr (BF3) {
+    if constexpr (FMT != 0) {
       // the split operands of three blocks at once do not fit the register file: one 16-pixel block at a time
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -371,8 +371,8 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
         mlp_layer<1, 4, 1, true>(enc1, g1, lds_w, lane);
 #pragma unroll
         for (int m = 0; m < 4; ++m) { c1[m][0] = enc1[m][0]; c1[4 + m][0] = cat[4 + m][p]; }
-        mlp_layer_bf3<8, 8, 1, true>(h1, c1, lds_w + WX, lane);
-        mlp_layer_bf3<8, 4, 1, true>(o1, h1, lds_w + WX + W1, lane);
+        mlp_layer_any<FMT, 8, 8, 1, true>(h1, c1, lds_w + WX, lane);
+        mlp_layer_any<FMT, 8, 4, 1, true>(o1, h1, lds_w + WX + W1, lane);
 #pragma unroll
         for (int o = 0; o < 4; ++o) h2[o][p] = o1[o][0];
       }
@@ -826,9 +826,10 @@ extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const flo
   constexpr int lds = 4 * (layer_floats(1, 4) + layer_floats(8, 8) + layer_floats(8, 4));
   {
     constexpr int lds3c = 4 * (layer_floats(1, 4) + layer_floats_bf3(8, 8) + layer_floats_bf3(8, 4));
+    constexpr int lds2c = 4 * (layer_floats(1, 4) + layer_floats_bf16(8, 8) + layer_floats_bf16(8, 4));
     PWCLO_REQUIRE(wfmt == PWCLO_WFMT_F32 || kp == 6 || kp == 32,
-                  "cv_fused_a2: the split format exists for 6 / 32 pixel slots only (got %d)", kp);
-    PWCLO_REQUIRE_PACKED("cv_fused_a2", wfmt, packed_floats, lds / 4, lds3c / 4);
+                  "cv_fused_a2: the reduced formats exist for 6 / 32 pixel slots only (got %d)", kp);
+    PWCLO_REQUIRE_PACKED("cv_fused_a2", wfmt, packed_floats, lds / 4, lds3c / 4, lds2c / 4);
   }
   static bool attr32 = false, attr16 = false, attr8 = false, attr16w = false, attr8w = false, attr6 = false;
   static const int wide = fl_tuning("PWCLO_FL_WIDE", 1);
@@ -837,9 +838,18 @@ extern "C" void cv_fused_a2_kernel_wrapper(int b, int n, int s, int k, const flo
   if (wfmt == PWCLO_WFMT_BF16X3) {     // opt-in split path (mlp_core.hpp)
     constexpr int lds3 = 4 * (layer_floats(1, 4) + layer_floats_bf3(8, 8) + layer_floats_bf3(8, 4));
     static bool b6 = false, b6s = false, b32 = false;
-    if (kp == 6 && t6 <= 2048) launch_persistent<4>(cv_a2_dense6_kernel<4, true>, b6s, lds3, t6, a);
-    else if (kp == 6) launch_persistent<8>(cv_a2_dense6_kernel<8, true>, b6, lds3, t6, a);
-    else launch_persistent<8>(cv_a2_kernel<32, 2, 8, true>, b32, lds3, tiles_of(b, s, 32, 2), a);
+    if (kp == 6 && t6 <= 2048) launch_persistent<4>(cv_a2_dense6_kernel<4, 1>, b6s, lds3, t6, a);
+    else if (kp == 6) launch_persistent<8>(cv_a2_dense6_kernel<8, 1>, b6, lds3, t6, a);
+    else launch_persistent<8>(cv_a2_kernel<32, 2, 8, 1>, b32, lds3, tiles_of(b, s, 32, 2), a);
+    check_launch("cv_fused_a2");
+    return;
+  }
+  if (wfmt == PWCLO_WFMT_BF16) {
+    constexpr int lds2 = 4 * (layer_floats(1, 4) + layer_floats_bf16(8, 8) + layer_floats_bf16(8, 4));
+    static bool c6 = false, c6s = false, c32 = false;
+    if (kp == 6 && t6 <= 2048) launch_persistent<4>(cv_a2_dense6_kernel<4, 2>, c6s, lds2, t6, a);
+    else if (kp == 6) launch_persistent<8>(cv_a2_dense6_kernel<8, 2>, c6, lds2, t6, a);
+    else launch_persistent<8>(cv_a2_kernel<32, 2, 8, 2>, c32, lds2, tiles_of(b, s, 32, 2), a);
     check_launch("cv_fused_a2");
     return;
   }

@@ -224,28 +224,98 @@ __device__ __forceinline__ void mlp_layer_bf3(f32x4 (&out)[NBO][P], const f32x4 
   });
 }
 
-// Layer dispatch used by the stack kernels: BF3 selects the split path (needs an even NBI).
-template <bool BF3, int NBI, int NBO, int P, bool RELU>
+// ---- bf16 layer (dtype = "bf16": BASELINE configs[4]) ----------------------------------------------------------
+// Weights and activations rounded ONCE to bf16 (round to nearest even), products accumulated in fp32 by
+// v_mfma_f32_16x16x32_bf16: 16 matrix cycles per 32 input channels (fp32 path: 256), 1 KiB of LDS per (o, mp) tile
+// (fp32 path: 2 KiB).  Same register layout as the split path above with only its `hi` term.  Bias / hoisted seeds,
+// accumulation, ReLU, pooling and softmax stay fp32; coordinates, distances and indices never pass through here.
+constexpr int BF16_TILE_FLOATS = 256;   // 64 lanes x 8 bf16 = 1 KiB per (o, mp) tile
+constexpr int layer_floats_bf16(int nbi, int nbo) { return nbo * (nbi / 2) * BF16_TILE_FLOATS + nbo * 16; }
+
+__device__ __forceinline__ bf16x8 to_bf16x8(const f32x4 a, const f32x4 b) {
+  bf16x8 r;
+  r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+  r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+  return r;
+}
+
+template <int NBI, int NBO, int P, bool RELU, typename Init>
+__device__ __forceinline__ void mlp_layer_bf16_init(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
+                                                    const float *w, int lane, Init init) {
+  static_assert(NBI % 2 == 0, "a K = 32 step consumes two 16-channel blocks");
+  constexpr int NP = NBI / 2;
+  bf16x8 x[NP][P];
+#pragma unroll
+  for (int mp = 0; mp < NP; ++mp)
+#pragma unroll
+    for (int p = 0; p < P; ++p) x[mp][p] = to_bf16x8(in[2 * mp][p], in[2 * mp + 1][p]);
+  const float *wl = w + lane * 4;                      // 16 bytes per lane
+#pragma unroll
+  for (int o = 0; o < NBO; ++o) {
+    f32x4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = init(o, p);
+#pragma unroll
+    for (int mp = 0; mp < NP; ++mp) {
+      const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wl + (o * NP + mp) * BF16_TILE_FLOATS);
+#pragma unroll
+      for (int p = 0; p < P; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, x[mp][p], acc[p], 0, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (RELU) {
+        f32x4 v = acc[p];
+        v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+        out[o][p] = v;
+      } else {
+        out[o][p] = acc[p];
+      }
+    }
+  }
+}
+
+template <int NBI, int NBO, int P, bool RELU>
+__device__ __forceinline__ void mlp_layer_bf16(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
+                                               const float *w, int lane) {
+  const float *bias = w + NBO * (NBI / 2) * BF16_TILE_FLOATS + 4 * (lane >> 4);
+  mlp_layer_bf16_init<NBI, NBO, P, RELU>(out, in, w, lane, [&](int o, int) {
+    return *reinterpret_cast<const f32x4 *>(bias + 16 * o);
+  });
+}
+
+// Layer dispatch used by the stack kernels.  FMT: 0 = fp32 MFMA, 1 = three-term bf16 split, 2 = bf16 (the reduced
+// formats need an even NBI; odd layers -- lone geometry blocks -- always run the fp32 MFMA).
+template <int FMT, int NBI, int NBO, int P, bool RELU>
 __device__ __forceinline__ void mlp_layer_any(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
                                               const float *w, int lane) {
-  if constexpr (BF3 && NBI % 2 == 0) mlp_layer_bf3<NBI, NBO, P, RELU>(out, in, w, lane);
+  if constexpr (FMT == 1 && NBI % 2 == 0) mlp_layer_bf3<NBI, NBO, P, RELU>(out, in, w, lane);
+  else if constexpr (FMT == 2 && NBI % 2 == 0) mlp_layer_bf16<NBI, NBO, P, RELU>(out, in, w, lane);
   else mlp_layer<NBI, NBO, P, RELU>(out, in, w, lane);
 }
-template <bool BF3>
+template <int FMT, int NBI, int NBO, int P, bool RELU, typename Init>
+__device__ __forceinline__ void mlp_layer_any_init(f32x4 (&out)[NBO][P], const f32x4 (&in)[NBI][P],
+                                                   const float *w, int lane, Init init) {
+  if constexpr (FMT == 1 && NBI % 2 == 0) mlp_layer_bf3_init<NBI, NBO, P, RELU>(out, in, w, lane, init);
+  else if constexpr (FMT == 2 && NBI % 2 == 0) mlp_layer_bf16_init<NBI, NBO, P, RELU>(out, in, w, lane, init);
+  else mlp_layer_init<NBI, NBO, P, RELU>(out, in, w, lane, init);
+}
+template <int FMT>
 constexpr int layer_floats_any(int nbi, int nbo) {
-  return (BF3 && nbi % 2 == 0) ? layer_floats_bf3(nbi, nbo) : layer_floats(nbi, nbo);
+  return (FMT == 1 && nbi % 2 == 0) ? layer_floats_bf3(nbi, nbo)
+         : (FMT == 2 && nbi % 2 == 0) ? layer_floats_bf16(nbi, nbo) : layer_floats(nbi, nbo);
 }
 
 // The format of a packed weight buffer is a property of the BUFFER, fixed when it was packed (fused.py records it
 // on the packed object): the stack launchers take it as an explicit argument `wfmt` together with the buffer's
 // length in floats, and refuse a length that does not match the layout the selected kernel will index
 // (a buffer packed in one format and launched as the other would otherwise be read out of bounds, silently).
-enum : int { PWCLO_WFMT_F32 = 0, PWCLO_WFMT_BF16X3 = 1 };
-#define PWCLO_REQUIRE_PACKED(what, wfmt, packed_floats, floats_f32, floats_bf3)                                  \
+enum : int { PWCLO_WFMT_F32 = 0, PWCLO_WFMT_BF16X3 = 1, PWCLO_WFMT_BF16 = 2 };
+#define PWCLO_REQUIRE_PACKED(what, wfmt, packed_floats, floats_f32, floats_bf3, floats_bf16)                     \
   do {                                                                                                           \
-    PWCLO_REQUIRE((wfmt) == PWCLO_WFMT_F32 || (wfmt) == PWCLO_WFMT_BF16X3, what ": unknown weight format %d",     \
+    PWCLO_REQUIRE((wfmt) >= PWCLO_WFMT_F32 && (wfmt) <= PWCLO_WFMT_BF16, what ": unknown weight format %d",        \
                   (int)(wfmt));                                                                                  \
-    const int expect_ = (wfmt) == PWCLO_WFMT_BF16X3 ? (int)(floats_bf3) : (int)(floats_f32);                       \
+    const int expect_ = (wfmt) == PWCLO_WFMT_BF16X3 ? (int)(floats_bf3)                                           \
+                        : (wfmt) == PWCLO_WFMT_BF16 ? (int)(floats_bf16) : (int)(floats_f32);                      \
     PWCLO_REQUIRE((packed_floats) == expect_, what ": packed weights hold %d floats, format %d needs %d",          \
                   (int)(packed_floats), (int)(wfmt), expect_);                                                   \
   } while (0)

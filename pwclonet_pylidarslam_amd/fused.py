@@ -49,20 +49,36 @@ def pack_layer(w, b, phys_map, nbo=None):
     return torch.cat((wp, bias)).contiguous()
 
 
-WFMT_F32, WFMT_BF16X3 = 0, 1     # include/pwclo_ops.h: packed-weight format of a stack (csrc/mlp_core.hpp)
+WFMT_F32, WFMT_BF16X3, WFMT_BF16 = 0, 1, 2     # include/pwclo_ops.h: packed-weight format of a stack (csrc/mlp_core.hpp)
+_DTYPE_WFMT = {"f32": WFMT_F32, "fp32": WFMT_F32, "float32": WFMT_F32, "bf16x3": WFMT_BF16X3, "bf16": WFMT_BF16,
+               "bfloat16": WFMT_BF16}
+_forced_wfmt = None
+
+
+@contextlib.contextmanager
+def packing_dtype(dtype):
+    """``with packing_dtype("bf16"): ...``: objects packed inside use that format ("f32", "bf16x3", "bf16")."""
+    global _forced_wfmt
+    saved, _forced_wfmt = _forced_wfmt, (None if dtype is None else _DTYPE_WFMT[str(dtype).replace("torch.", "")])
+    try:
+        yield
+    finally:
+        _forced_wfmt = saved
 
 
 def default_wfmt():
-    """Format new packed objects are built in: fp32 operand tiles unless PWCLO_BF16X3=1 asks for the opt-in
-    three-term bf16 split.  Read ONCE per object, at pack time; the object records it
-    (``.wfmt``) and passes it with every launch, so a later change of the variable cannot make a kernel
-    index a buffer of the other layout."""
+    """Format new packed objects are built in: what ``packing_dtype`` / ``prepare_fused(dtype=...)`` asked for, else
+    fp32 operand tiles unless PWCLO_BF16X3=1 selects the opt-in three-term bf16 split.  Read
+    ONCE per object, at pack time; the object records it (``.wfmt``) and passes it with every launch, so a later
+    change cannot make a kernel index a buffer of another layout."""
+    if _forced_wfmt is not None:
+        return _forced_wfmt
     return WFMT_BF16X3 if os.environ.get("PWCLO_BF16X3", "0") != "0" else WFMT_F32
 
 
 def _kname(name, wfmt, split_capable=True):
-    """Kernel name as rocprofv3 prints it: the stack kernels carry a trailing `bool BF3` template argument."""
-    return name[:-1] + (", true>" if split_capable and wfmt == WFMT_BF16X3 else ", false>")
+    """Kernel name as rocprofv3 prints it: the stack kernels carry a trailing `int FMT` template argument."""
+    return name[:-1] + (", %d>" % (wfmt if split_capable else 0))
 
 
 def _a2_kernel_name(kp, B, S, wfmt):
@@ -94,6 +110,24 @@ def pack_layer_bf3(w, b, phys_map, nbo=None):
     lo = (r1 - mid.float()).to(torch.bfloat16)
     tiles = torch.stack((hi, mid, lo), dim=2).contiguous()            # (o, mp, split, lane, 8)
     packed = tiles.view(torch.int16).reshape(-1).view(torch.float32)
+    bias = torch.zeros(16 * nbo, dtype=torch.float32, device=w.device)
+    bias[:cout] = b
+    return torch.cat((packed, bias)).contiguous()
+
+
+def pack_layer_bf16(w, b, phys_map, nbo=None):
+    """Pack one folded layer for ``mlp_layer_bf16`` (csrc/mlp_core.hpp): per (o, mp) tile [lane][8 bf16] in the
+    element order of ``pack_layer_bf3``, every weight rounded once to bf16 (round to nearest even); fp32 bias."""
+    cout, _ = w.shape
+    nbi = len(phys_map) // 16
+    assert len(phys_map) == 16 * nbi and nbi % 2 == 0
+    nbo = nbo or (cout + 15) // 16
+    pm = torch.as_tensor(phys_map, dtype=torch.long, device=w.device)
+    wphys = torch.zeros((16 * nbo, 16 * nbi), dtype=torch.float32, device=w.device)
+    valid = pm >= 0
+    wphys[:cout, valid] = w[:, pm[valid]]
+    wt = wphys.view(nbo, 16, nbi // 2, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(nbo, nbi // 2, 64, 8)
+    packed = wt.to(torch.bfloat16).contiguous().view(torch.int16).reshape(-1).view(torch.float32)
     bias = torch.zeros(16 * nbo, dtype=torch.float32, device=w.device)
     bias[:cout] = b
     return torch.cat((packed, bias)).contiguous()
@@ -424,6 +458,8 @@ def pack_layer_any(w, b, phys_map, nbo=None, wfmt=WFMT_F32):
     blocks (csrc/mlp_core.hpp: mlp_layer_any / layer_floats_any), ``pack_layer`` otherwise."""
     if wfmt == WFMT_BF16X3 and (len(phys_map) // 16) % 2 == 0:
         return pack_layer_bf3(w, b, phys_map, nbo)
+    if wfmt == WFMT_BF16 and (len(phys_map) // 16) % 2 == 0:
+        return pack_layer_bf16(w, b, phys_map, nbo)
     return pack_layer(w, b, phys_map, nbo)
 
 

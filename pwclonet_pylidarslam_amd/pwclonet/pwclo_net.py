@@ -124,15 +124,21 @@ class PWCLONet(nn.Module):
         self._fused = None
 
     # ---- fused eval-mode path ---------------------------------------------------------------------
-    def prepare_fused(self):
-        """Fold BatchNorm and pack the weights for the fused kernels (eval mode only).  The packed copy is tied
+    def prepare_fused(self, dtype=None):
+        """Fold BatchNorm and pack the weights for the fused kernels (eval mode only).  ``dtype``: "f32" (default:
+        fp32 MFMA, the parity path), "bf16" (BASELINE configs[4]: stack layers on v_mfma_f32_16x16x32_bf16 with weights
+        and activations rounded to bf16, fp32 accumulation; coordinates, distances, FPS indices and neighbour lists
+        stay fp32 / exact) or "bf16x3" (the opt-in three-term split).  The packed copy is tied
         to the parameters it was made from: ``train()``, ``load_state_dict()``, ``.to()`` / ``.cuda()`` /
         ``.float()`` (anything that goes through ``_apply``) drop it, and an in-place edit of any parameter or
         buffer (optimizer step, ``copy_``) is noticed through the tensors' version counters at the next eager
         forward, which re-packs."""
-        from ..fused import FusedPWCLONet
+        from ..fused import FusedPWCLONet, packing_dtype
         self.eval()
-        self._fused = FusedPWCLONet(self)
+        if dtype is not None:
+            self._fused_dtype = dtype
+        with packing_dtype(getattr(self, "_fused_dtype", None)):
+            self._fused = FusedPWCLONet(self)
         self._fused_tensors = list(self.parameters()) + list(self.buffers())
         self._fused_versions = self._state_versions()
         return self

@@ -441,3 +441,43 @@ def test_log_dict_under_graph_replay_is_per_batch(cuda):
         net.pose_calculator_4.conv1d_t.conv.bias.add_(0.25)
     after = net(x1, None, x2, None)[0]
     assert (after[:, 3, :3] - before[:, 3, :3]).abs().min().item() > 0.2      # level-4 translation moved by the edit
+
+
+@pytest.mark.parametrize("case", ["n1024_b2", "n8192_b1"])
+def test_bf16_dtype_path_against_fp32_golden(cuda, case):
+    """BASELINE configs[4] / SURVEY section 8d "Config 5": ``prepare_fused(dtype="bf16")`` runs the stack layers on
+    v_mfma_f32_16x16x32_bf16 (weights and activations rounded once to bf16, fp32 accumulate); coordinates, distances and
+    indices stay fp32.  Bars: everything computed from coordinates alone is BIT-EXACT with the fp32 path (sampled
+    coordinates, the neighbour lists that do not depend on a predicted pose); features and poses are compared with the
+    fp32 reference golden output within a stated bf16 bound: level-3 features 2e-2 of their scale (three stacked bf16
+    layers, 8 mantissa bits each), poses 3e-2 of the pose scale.  The measured figures are printed."""
+    z = np.load(os.path.join(GOLDEN, "pwclonet_%s.npz" % case))
+    meta = json.loads(str(z["meta"]))
+    if meta["generator"] == "uniform":
+        pc1, pc2 = synthetic.uniform_pair(meta["seed"], meta["npoints"], meta["batch"])
+    else:
+        pc1, pc2, _, _ = synthetic.kitti_like_pair(meta["seed"], meta["npoints"], meta["batch"])
+    x1 = torch.from_numpy(pc1[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    x2 = torch.from_numpy(pc2[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    net = _net(cuda)
+    pose32, inter32 = fused.FusedPWCLONet(net)(x1, x2, return_intermediates=True)
+    with fused.packing_dtype("bf16"):
+        f16 = fused.FusedPWCLONet(net)
+    assert f16.sa[1].wfmt == fused.WFMT_BF16 and f16.pwr[0]["cv"].wfmt == fused.WFMT_BF16
+    pose, inter = f16(x1, x2, return_intermediates=True)
+    # exact: sampling and every neighbour list that depends on coordinates only
+    assert torch.equal(inter["x11"], inter32["x11"])
+    assert torch.equal(inter["x11"].cpu(), torch.from_numpy(z["f1.psa_1.new_xyz"]))
+    for key in ("psa_1.knn_idx", "psa_2.knn_idx", "psa_3.knn_idx", "psa_4.knn_idx", "cv3.idx_q", "cv3.idx", "ffe.knn_idx",
+                "pwr3.up.idx", "pwr2.up.idx", "pwr1.up.idx"):
+        assert torch.equal(inter["lists"][key], inter32["lists"][key]), key
+    # bf16 bound on features and poses against the fp32 reference golden values
+    ref = torch.from_numpy(z["pose_params"])
+    f13, ref13 = pm(inter["f13"]).cpu(), torch.from_numpy(z["f1.psa_3.new_features"])
+    e13 = (f13 - ref13).abs().max().item() / ref13.abs().max().item()
+    err, scale = (pose.cpu() - ref).abs().max().item(), ref.abs().max().item()
+    print("\nbf16 %s: level-3 features max err %.2e of scale, pose max |d| %.2e (scale %.3f, ratio %.2e); fp32 path ratio %.2e"
+          % (case, e13, err, scale, err / scale, (pose32.cpu() - ref).abs().max().item() / scale))
+    assert e13 <= 2e-2, e13
+    assert err <= 3e-2 * scale, (err, scale)
+    assert not torch.equal(pose, pose32)                     # it really is the other arithmetic
