@@ -39,8 +39,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import pwclonet_pylidarslam_amd  # noqa: E402
 
-pwclonet_pylidarslam_amd.configure_hw_queues(8)   # explicit, before the first HIP call: 4 batches in flight need > 4 queues
-
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -477,6 +475,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing only: rendezvous + fences + aggregation over gloo with a host sleep as the step")
     args = ap.parse_args()
+    # explicit, before the first HIP call of the process: 4 batches in flight need more than the default 4 hardware
+    # queues (importing this file -- tests and tools do, for make_batch -- configures nothing)
+    pwclonet_pylidarslam_amd.configure_hw_queues(8)
 
     if args.steps is None:
         args.steps = 5 if args.config == 5 else 40

@@ -134,6 +134,21 @@ void knn_point_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz
  * `workspace` may be NULL; also used when s < 256, where the build does not amortise).
  * Bit-identical output to knn_point_kernel_wrapper. */
 long long knn_point_workspace_bytes(int b, int n);
+/* The two passes of the pruned search separately, so that ONE build of a cloud's search structure serves several
+ * searches and the slab-pruned sampler below: workspace of knn_point_build_bytes(b, n) bytes (64 <= n <= 16384);
+ * slab_tab (optional, b*32 ints): (padded first row, row count) of the cloud's knn_point_slabs(n) <= 16 x-slabs. */
+long long knn_point_build_bytes(int b, int n);
+int knn_point_slabs(int n);
+void knn_build_kernel_wrapper(int b, int n, const float *xyz, void *workspace, int *slab_tab);
+void knn_point_prebuilt_kernel_wrapper(int b, int n, int s, int nsample, const float *new_xyz, int *idx, float *dist,
+                                       void *workspace);
+/* furthest_point_sampling_chain_kernel_wrapper for a cloud whose search structure exists (knn_point_slabs(n) == 8,
+ * n >= 4096: level 1 of the pyramid): the distance update of a wave is skipped, exactly, whenever the new sample
+ * cannot lower any running distance inside the wave's x-slab (csrc/sampling.hip: fps_slab_kernel).  status: b ints
+ * (device) the two kernels use to divide the clouds between them.  Same idxs / new_xyz / tie_out as the chain entry. */
+void furthest_point_sampling_slab_kernel_wrapper(int b, int n, int m, const float *dataset, int *idxs,
+                                                 float *new_xyz, int *tie_out, int tie_iters,
+                                                 const void *knn_workspace, const int *slab_tab, int *status);
 void knn_point_ws_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz,
                                  const float *new_xyz, int *idx, float *dist, void *workspace);
 

@@ -38,6 +38,11 @@ SIGNATURES = {
     "knn_point_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
     "knn_point_workspace_bytes": ([_i, _i], ctypes.c_longlong),
     "knn_point_ws_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F, _F], None),
+    "knn_point_build_bytes": ([_i, _i], ctypes.c_longlong),
+    "knn_point_slabs": ([_i], _i),
+    "knn_build_kernel_wrapper": ([_i, _i, _F, _F, _F], None),
+    "knn_point_prebuilt_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
+    "furthest_point_sampling_slab_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F, _i, _F, _F, _F], None),
     "quat_warp_kernel_wrapper": ([_i, _i, _F, _F, _F, _F], None),
     "sa_fused_kernel_wrapper": ([_i] * 8 + [_F] * 6, None),
     "furthest_point_sampling_xyz_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F], None),

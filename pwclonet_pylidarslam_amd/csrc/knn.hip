@@ -296,7 +296,8 @@ template <int R>
 __global__ __launch_bounds__(KB_THREADS) void knn_build_kernel(int n, int nslab, int nblk_max,
                                                                const float *__restrict__ xyz,
                                                                float4 *__restrict__ rows,
-                                                               float4 *__restrict__ boxes) {
+                                                               float4 *__restrict__ boxes,
+                                                               int *__restrict__ slab_tab) {
   TraceScope trace_scope_(TK_KNN_BUILD);
   __shared__ int hist[KB_BINS];      // x histogram, then slab of every x-bin
   __shared__ int hist2[KB_BINS];     // (slab, z-bin) histogram, then row offset of every bin
@@ -375,6 +376,13 @@ __global__ __launch_bounds__(KB_THREADS) void knn_build_kernel(int n, int nslab,
       start += (cnt + 63) / 64 * 64;
     }
     red[0][0] = __int_as_float(start);                           // rows in use (end of the last slab)
+    if (slab_tab != nullptr) {                                   // (padded first row, rows) of every slab, for the
+      int *tab = slab_tab + (size_t)blockIdx.x * 32;             // slab-pruned sampler (sampling.hip: fps_slab_kernel)
+      for (int sl = 0; sl < 16; ++sl) {
+        tab[2 * sl] = sl < nslab ? wsum[sl] : 0;
+        tab[2 * sl + 1] = sl < nslab ? slab_count[sl] : 0;
+      }
+    }
   }
   __syncthreads();
   const int my_slab = tid / zb;
@@ -776,17 +784,9 @@ extern "C" long long knn_point_workspace_bytes(int b, int n) {
   return (long long)b * nblk * (64 * 16 + 32);
 }
 
-extern "C" void knn_point_ws_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz,
-                                            const float *new_xyz, int *idx, float *dist,
-                                            void *workspace) {
-  if (b <= 0 || s <= 0) return;
-  if (workspace == nullptr || knn_point_workspace_bytes(b, n) == 0 || s < knn_min_s()) {
-    knn_point_kernel_wrapper(b, n, s, nsample, xyz, new_xyz, idx, dist);   // too few queries to amortise the build
-    return;
-  }
-  PWCLO_REQUIRE(nsample >= 1 && nsample <= 64, "knn_point: nsample=%d outside [1,64]", nsample);
-  PWCLO_REQUIRE(nsample <= n, "knn_point: nsample=%d exceeds the number of points n=%d", nsample, n);
-  PWCLO_REQUIRE(b <= 65535, "knn_point: b=%d exceeds the grid limit", b);
+// Build pass alone: sorted rows + block boxes into `workspace` (knn_point_workspace_bytes(b, n) bytes) and, when
+// slab_tab != NULL, 32 ints per cloud: (padded first row, row count) of up to 16 x-slabs.
+static bool knn_build_launch(int b, int n, const float *xyz, void *workspace, int *slab_tab) {
   const int nslab = knn_slabs(n);
   const int nblk = (n + 63) / 64 + nslab;
   float4 *rows = reinterpret_cast<float4 *>(workspace);
@@ -794,13 +794,22 @@ extern "C" void knn_point_ws_kernel_wrapper(int b, int n, int s, int nsample, co
   const int regs = ceil_div(n, KB_THREADS);
 #define KB_CASE(RR)                                                                                   \
   hipLaunchKernelGGL(knn_build_kernel<RR>, dim3(b), dim3(KB_THREADS), 0, current_stream(), n, nslab, nblk, \
-                     xyz, rows, boxes);
+                     xyz, rows, boxes, slab_tab);
   if (regs <= 1) { KB_CASE(1) }
   else if (regs <= 2) { KB_CASE(2) }
   else if (regs <= 4) { KB_CASE(4) }
   else if (regs <= 8) { KB_CASE(8) }
   else { KB_CASE(16) }
 #undef KB_CASE
+  return check_launch("knn_point(build)");
+}
+
+static void knn_search_launch(int b, int n, int s, int nsample, const float *new_xyz, int *idx, float *dist,
+                              void *workspace) {
+  const int nslab = knn_slabs(n);
+  const int nblk = (n + 63) / 64 + nslab;
+  float4 *rows = reinterpret_cast<float4 *>(workspace);
+  float4 *boxes = rows + (size_t)b * nblk * 64;
   // K <= 32: several queries per wave (knn_rows_kernel); PWCLO_KNN_ROWS=0 keeps one query per wave (A/B switch)
   static int use_rows = -1;
   if (use_rows < 0) { const char *e = getenv("PWCLO_KNN_ROWS"); use_rows = e ? atoi(e) : 1; }
@@ -821,4 +830,46 @@ extern "C" void knn_point_ws_kernel_wrapper(int b, int n, int s, int nsample, co
   hipLaunchKernelGGL(knn_pruned_kernel, dim3(ceil_div(s, KNN_WAVES), b), dim3(KNN_WAVES * 64), 0,
                      current_stream(), nblk, s, nsample, rows, boxes, new_xyz, idx, dist);
   check_launch("knn_point(pruned)");
+}
+
+extern "C" void knn_point_ws_kernel_wrapper(int b, int n, int s, int nsample, const float *xyz,
+                                            const float *new_xyz, int *idx, float *dist,
+                                            void *workspace) {
+  if (b <= 0 || s <= 0) return;
+  if (workspace == nullptr || knn_point_workspace_bytes(b, n) == 0 || s < knn_min_s()) {
+    knn_point_kernel_wrapper(b, n, s, nsample, xyz, new_xyz, idx, dist);   // too few queries to amortise the build
+    return;
+  }
+  PWCLO_REQUIRE(nsample >= 1 && nsample <= 64, "knn_point: nsample=%d outside [1,64]", nsample);
+  PWCLO_REQUIRE(nsample <= n, "knn_point: nsample=%d exceeds the number of points n=%d", nsample, n);
+  PWCLO_REQUIRE(b <= 65535, "knn_point: b=%d exceeds the grid limit", b);
+  if (!knn_build_launch(b, n, xyz, workspace, nullptr)) return;
+  knn_search_launch(b, n, s, nsample, new_xyz, idx, dist, workspace);
+}
+
+// The two passes separately: one build of a cloud's search structure can serve several searches AND the
+// slab-pruned furthest point sampling of the same cloud (furthest_point_sampling_slab_kernel_wrapper).
+extern "C" void knn_build_kernel_wrapper(int b, int n, const float *xyz, void *workspace, int *slab_tab) {
+  if (b <= 0) return;
+  PWCLO_REQUIRE(workspace != nullptr && n >= 64 && n <= pwclo::KNN_MAX_SORT,
+                "knn_build: n=%d outside [64,%d] or no workspace", n, pwclo::KNN_MAX_SORT);
+  PWCLO_REQUIRE(b <= 65535, "knn_build: b=%d exceeds the grid limit", b);
+  knn_build_launch(b, n, xyz, workspace, slab_tab);
+}
+
+extern "C" void knn_point_prebuilt_kernel_wrapper(int b, int n, int s, int nsample, const float *new_xyz, int *idx,
+                                                  float *dist, void *workspace) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(workspace != nullptr && n >= 64 && n <= pwclo::KNN_MAX_SORT,
+                "knn_point(prebuilt): n=%d outside [64,%d] or no workspace", n, pwclo::KNN_MAX_SORT);
+  PWCLO_REQUIRE(nsample >= 1 && nsample <= 64 && nsample <= n, "knn_point(prebuilt): nsample=%d invalid for n=%d", nsample, n);
+  PWCLO_REQUIRE(b <= 65535, "knn_point(prebuilt): b=%d exceeds the grid limit", b);
+  knn_search_launch(b, n, s, nsample, new_xyz, idx, dist, workspace);
+}
+
+extern "C" int knn_point_slabs(int n) { return knn_slabs(n); }
+extern "C" long long knn_point_build_bytes(int b, int n) {        // workspace of the build for ANY 64 <= n <= 16384
+  if (n < 64 || n > pwclo::KNN_MAX_SORT) return 0;
+  const long long nblk = (n + 63) / 64 + knn_slabs(n);
+  return (long long)b * nblk * (64 * 16 + 32);
 }

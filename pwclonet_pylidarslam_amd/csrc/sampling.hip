@@ -79,9 +79,11 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
                                                     int *__restrict__ idxs,
                                                     float *__restrict__ new_xyz,
                                                     int *__restrict__ tie_out, int tie_iters,
-                                                    const int *__restrict__ prefix_in) {
+                                                    const int *__restrict__ prefix_in,
+                                                    const int *__restrict__ done = nullptr) {
   TraceScope trace_scope_(TK_FPS);
   constexpr int PPT = I << E;
+  if (done != nullptr && done[blockIdx.x] != 0) return;   // this cloud was sampled by fps_slab_kernel (workgroup-uniform)
   if (prefix_in != nullptr && prefix_in[blockIdx.x * FPS_CHAIN_INTS] == 0) {       // workgroup-uniform
     const int *rec = prefix_in + blockIdx.x * FPS_CHAIN_INTS;
     const int nev = rec[1];
@@ -240,6 +242,224 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
     // and won with the same value (the other tied point, alone at V); anything else -> fallback.
     int *rec = tie_out + blockIdx.x * FPS_CHAIN_INTS;
     const bool enough = m >= tie_iters + 2;                 // decisions tie_iters-1 and tie_iters both made
+    __syncthreads();
+    if (enough) {
+      for (int i = 1 + tid; i < tie_iters; i += T) {
+        const int st = cstat[i];
+        if (st == 0) continue;
+        if (st == 2 || cstat[i + 1] != 0 || cvals[i + 1] != cvals[i] || (i > 1 && cstat[i - 1] != 0)) {
+          cmeta[1] = 1;
+        } else {
+          const int e = atomicAdd(&cmeta[0], 1);
+          if (e < FPS_CHAIN_MAXEV) rec[2 + e] = i; else cmeta[1] = 1;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      rec[0] = (!enough || cmeta[1] != 0) ? 1 : 0;
+      rec[1] = cmeta[0] < FPS_CHAIN_MAXEV ? cmeta[0] : FPS_CHAIN_MAXEV;
+    }
+  }
+}
+
+// ---- bucket-pruned sampler (level 1 of the pyramid: n ~ 8192) ---------------------------------------------------
+// The distance update touches every point every iteration although, once a few dozen samples exist, a new sample
+// can only lower the running distance of points near it.  Exact pruning, per BUCKET of 64 points: the neighbour
+// search of the same cloud has already sorted it by (x-slab, z-bin) (knn_build_kernel), so 64 consecutive valid
+// rows form a compact cell.  Bucket b = rows [64b, 64b + 64) lives in slot b / 8 of wave b % 8 (neighbouring cells
+// on different waves and SIMDs), one point per lane.  With (lo, hi) the bucket's bounding box and V its largest
+// running distance, the bucket's update can be skipped whenever
+//     bd = gx*gx + gy*gy + gz*gz >= V,   g = max(lo - s, s - hi, 0) per axis (s = the new sample),
+// because every point p of the bucket has d(p, s) >= bd in fp32 as well -- subtraction, squaring and the two
+// additions are monotone under round-to-nearest and the expression is the one the update evaluates -- so
+// min(d, running) = running for all of them and the bucket's cached summary (max, best priority at the max,
+// "attained twice") is still what a full update would produce.  The bucket holding the sample itself is never
+// skipped (bd = 0).  Lane j < I of a wave holds bucket j's box and summary; per iteration the 16 bounds are one
+// vector expression, the wave updates only the buckets of the resulting mask (measured on the benchmark clouds:
+// ~4 of 128 per iteration, ~9 during the first 200) and re-reduces their summaries; a wave with an empty mask reuses
+// its cached arg-max.  Priorities derive from the ORIGINAL index each sorted row carries, hence the same winner as
+// fps_reg_kernel for every input (tests: lattice clouds, zero padding, chain records, benchmark clouds bit for bit).
+template <int T, int I>
+__global__ __launch_bounds__(T) void fps_slab_kernel(int n, int m, int bs, int log2bs, int nblk,
+                                                     const float4 *__restrict__ rows_all,
+                                                     const int *__restrict__ slab_tab,
+                                                     int *__restrict__ idxs, float *__restrict__ new_xyz,
+                                                     int *__restrict__ tie_out, int tie_iters,
+                                                     int *__restrict__ status, int dbg) {
+  TraceScope trace_scope_(TK_FPS);
+  constexpr int NW = T / 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int *tab = slab_tab + (size_t)blockIdx.x * 32;
+  int sstart[NW], scum[NW + 1];                             // slab s: rows [sstart[s], +count), valid ranks [scum[s], scum[s+1])
+  scum[0] = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { sstart[w] = tab[2 * w]; scum[w + 1] = scum[w] + tab[2 * w + 1]; }
+  if (tid == 0) status[blockIdx.x] = 1;
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [3] rotating
+  float4 *table = reinterpret_cast<float4 *>(smem + FPS_SLOT_BYTES);         // [n], by ORIGINAL index
+  unsigned *cvals = reinterpret_cast<unsigned *>(smem + FPS_SLOT_BYTES + (size_t)n * 16);
+  int *cstat = reinterpret_cast<int *>(cvals + (tie_iters + 2));
+  int *cmeta = reinterpret_cast<int *>(smem + 32);
+
+  const float4 *rows = rows_all + (size_t)blockIdx.x * nblk * 64;
+  int *out = idxs + (size_t)blockIdx.x * m;
+  float *oxyz = new_xyz ? new_xyz + (size_t)blockIdx.x * m * 3 : nullptr;
+
+  float x[I], y[I], z[I];
+  int td[I];
+  unsigned pri[I];
+  const float INF = __int_as_float(0x7f800000);
+  // bucket j of this wave: box and summary live in lane j
+  float blox = INF, bloy = INF, bloz = INF, bhix = -INF, bhiy = -INF, bhiz = -INF;
+#pragma unroll
+  for (int j = 0; j < I; ++j) {
+    const int r = (j * NW + wave) * 64 + lane;               // rank among the cloud's valid rows
+    float px = 0.f, py = 0.f, pz = 0.f, t0 = -1.0f;
+    unsigned pr = 0xFFFFFFFFu;
+    float lx = INF, ly = INF, lz = INF, hx = -INF, hy = -INF, hz = -INF;
+    if (r < n) {
+      int row = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if (r >= scum[w] && r < scum[w + 1]) row = sstart[w] + (r - scum[w]);
+      const float4 c = rows[row];
+      px = c.x; py = c.y; pz = c.z;
+      const unsigned k = __float_as_uint(c.w);              // original index
+      pr = (fps_bitrev(k & (unsigned)(bs - 1), log2bs) << PRI_SHIFT) | (k >> log2bs);
+      const float mag = (px * px) + (py * py) + (pz * pz);
+      if (!((double)mag <= 1e-3)) {                         // never-eligible points stay outside the box
+        t0 = 1e10f;
+        lx = hx = px; ly = hy = py; lz = hz = pz;
+      }
+      table[k] = make_float4(px, py, pz, 0.f);
+    }
+    x[j] = px; y[j] = py; z[j] = pz; td[j] = __float_as_int(t0); pri[j] = pr;
+    lx = wave_allreduce_f32(lx, [](float a, float b) { return fminf(a, b); });
+    ly = wave_allreduce_f32(ly, [](float a, float b) { return fminf(a, b); });
+    lz = wave_allreduce_f32(lz, [](float a, float b) { return fminf(a, b); });
+    hx = wave_allreduce_f32(hx, [](float a, float b) { return fmaxf(a, b); });
+    hy = wave_allreduce_f32(hy, [](float a, float b) { return fmaxf(a, b); });
+    hz = wave_allreduce_f32(hz, [](float a, float b) { return fmaxf(a, b); });
+    if (lane == j) { blox = lx; bloy = ly; bloz = lz; bhix = hx; bhiy = hy; bhiz = hz; }
+  }
+  if (tid == 0) {
+    out[0] = 0;
+    slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull;
+    cmeta[0] = 0; cmeta[1] = 0;
+  }
+  if (tie_out != nullptr)
+    for (int i = tid; i < tie_iters + 2; i += T) { cstat[i] = 0; cvals[i] = 0u; }
+  __syncthreads();
+
+  // Running distances are kept as bits + 1 (0 = never a candidate), so that (distance, ~priority) is ONE unsigned
+  // 64-bit key per point and the in-lane arg-max is a 64-bit compare + two selects per slot.
+  unsigned tdm[I], npri[I];
+#pragma unroll
+  for (int j = 0; j < I; ++j) { tdm[j] = td[j] < 0 ? 0u : (unsigned)td[j] + 1u; npri[j] = ~pri[j]; }
+  // the wave's cached arg-max (valid while none of its buckets is updated)
+  unsigned wmax = 0u, wpri = 0xFFFFFFFFu;
+  bool wtie = false;
+  // Upper bound of EVERY running distance: the previous winner's value (it was the global maximum).  A bucket whose
+  // box is at least that far from the new sample cannot change; no per-bucket maximum has to be maintained.
+  unsigned gmax = 0x7FFFFFFFu;
+  int old = 0;
+  auto iteration = [&](auto track_tag, int it) {
+    constexpr bool TRACK = decltype(track_tag)::value;
+    const float4 p1 = table[old];
+    const float x1 = p1.x, y1 = p1.y, z1 = p1.z;
+    if (oxyz && tid == 0) {
+      oxyz[(it - 1) * 3 + 0] = x1; oxyz[(it - 1) * 3 + 1] = y1; oxyz[(it - 1) * 3 + 2] = z1;
+    }
+    // lane j: lower bound of d(p, sample) over bucket j's box, in the update's own arithmetic
+    const float gx = fmaxf(fmaxf(blox - x1, x1 - bhix), 0.f);
+    const float gy = fmaxf(fmaxf(bloy - y1, y1 - bhiy), 0.f);
+    const float gz = fmaxf(fmaxf(bloz - z1, z1 - bhiz), 0.f);
+    const float bd = gx * gx + gy * gy + gz * gz;
+    unsigned long long todo = __ballot(lane < I && (unsigned)__float_as_int(bd) + 1u < gmax);
+    if (dbg == 1 && it > 1) todo = 0ull;                    // timing probe: overhead floor (wrong results)
+    if (todo != 0ull) {
+      auto update = [&](auto jtag) {
+        constexpr int j = decltype(jtag)::value;
+        // opaque copies of the sample: without them the compiler hoists the distance arithmetic of ALL sixteen
+        // cases above the switch (speculation), i.e. it undoes the pruning
+        float sx = x1, sy = y1, sz = z1;
+        asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));
+        const float dx = x[j] - sx, dy = y[j] - sy, dz = z[j] - sz;
+        const float d = dx * dx + dy * dy + dz * dz;       // -ffp-contract=off: (a+b)+c, no FMA
+        tdm[j] = min((unsigned)__float_as_int(d) + 1u, tdm[j]);          // 0 (ineligible) stays 0
+      };
+      while (todo != 0ull) {
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        switch (j) {
+#define FSL_CASE(J) case J: if constexpr (J < I) update(std::integral_constant<int, J>{}); break;
+          FSL_CASE(0) FSL_CASE(1) FSL_CASE(2) FSL_CASE(3) FSL_CASE(4) FSL_CASE(5) FSL_CASE(6) FSL_CASE(7)
+          FSL_CASE(8) FSL_CASE(9) FSL_CASE(10) FSL_CASE(11) FSL_CASE(12) FSL_CASE(13) FSL_CASE(14) FSL_CASE(15)
+          FSL_CASE(16) FSL_CASE(17) FSL_CASE(18) FSL_CASE(19)
+#undef FSL_CASE
+          default: break;
+        }
+      }
+      // the lane's arg-max over its slots (independent 64-bit compares), then the wave's
+      unsigned bhi = 0u, blo = 0u, b2 = 0u;
+#pragma unroll
+      for (int j = 0; j < I; ++j) {
+        if (TRACK) asm("v_med3_u32 %0, %1, %2, %3" : "=v"(b2) : "v"(bhi), "v"(b2), "v"(tdm[j]));   // runner-up value
+        const unsigned long long kj = ((unsigned long long)tdm[j] << 32) | npri[j];
+        const bool better = kj > (((unsigned long long)bhi << 32) | blo);
+        bhi = better ? tdm[j] : bhi;
+        blo = better ? npri[j] : blo;
+      }
+      const bool lane_tie = TRACK && bhi != 0u && b2 == bhi;
+      wmax = wave_reduce_u32(bhi, OpMaxU32());
+      const bool holds = bhi == wmax && bhi != 0u;
+      wpri = ~wave_reduce_u32(holds ? blo : 0u, OpMaxU32());
+      if (TRACK) {
+        const unsigned long long hm = __ballot(holds);
+        wtie = (hm & (hm - 1ull)) != 0ull || __ballot(holds && lane_tie) != 0ull;
+      }
+    }
+    const unsigned long long wkey =
+        wmax == 0u ? 0ull : (((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wpri));
+    unsigned long long key = wkey;
+    {
+      unsigned long long *slot = slots + (it % 3);
+      if (lane == 0) atomicMax(slot, key);
+      __syncthreads();
+      key = *slot;
+      if (tid == 0) slots[(it + 2) % 3] = 0ull;
+    }
+    gmax = (unsigned)(key >> 32);                          // bits + 1 of the winner's distance: bounds every point
+    if (TRACK) {
+      // a tie = the GLOBAL maximum attained by two points: inside this wave (wtie) or by another wave (wkey != key)
+      const bool at_max = wmax != 0u && wmax == (unsigned)(key >> 32);
+      const bool tie = at_max && (wtie || wkey != key);
+      if (lane == 0 && (tie || key == 0ull)) cstat[it] = key == 0ull ? 2 : 1;
+      if (tid == 0) cvals[it] = (unsigned)(key >> 32);
+    }
+    if (key == 0ull) {
+      old = 0;
+    } else {
+      const unsigned p = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+      old = (int)fps_bitrev(p >> PRI_SHIFT, log2bs) + bs * (int)(p & ((1u << PRI_SHIFT) - 1u));
+    }
+    if (tid == 0) out[it] = old;
+  };
+  int it = 1;
+  const int tracked_end = tie_out != nullptr ? (tie_iters + 2 < m ? tie_iters + 2 : m) : 1;
+  for (; it < tracked_end; ++it) iteration(std::true_type{}, it);
+  for (; it < m; ++it) iteration(std::false_type{}, it);
+  if (oxyz && tid == 0) {
+    const float4 p = table[old];
+    oxyz[(m - 1) * 3 + 0] = p.x; oxyz[(m - 1) * 3 + 1] = p.y; oxyz[(m - 1) * 3 + 2] = p.z;
+  }
+  if (tie_out != nullptr) {      // judge the log exactly as fps_reg_kernel does
+    int *rec = tie_out + blockIdx.x * FPS_CHAIN_INTS;
+    const bool enough = m >= tie_iters + 2;
     __syncthreads();
     if (enough) {
       for (int i = 1 + tid; i < tie_iters; i += T) {
@@ -515,6 +735,9 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
   }
 }
 
+// Per-cloud "already sampled" flags of the launch being dispatched (set by the slab wrapper around fps_dispatch).
+static thread_local const int *t_done_flags = nullptr;
+
 template <int T, int E, int I>
 static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float *dataset, int *idxs,
                            float *new_xyz, int *tie_out, int tie_iters, const int *prefix_in) {
@@ -532,10 +755,10 @@ static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float 
       big_lds_enabled = true;
     }
     hipLaunchKernelGGL(kern, dim3(b), dim3(T), table_bytes, st, n, m, bs, log2bs, dataset, idxs, new_xyz, tie_out,
-                       tie_iters, prefix_in);
+                       tie_iters, prefix_in, t_done_flags);
   } else {
     hipLaunchKernelGGL((fps_reg_kernel<T, E, I, false>), dim3(b), dim3(T), FPS_SLOT_BYTES + chain_bytes, st, n, m,
-                       bs, log2bs, dataset, idxs, new_xyz, tie_out, tie_iters, prefix_in);
+                       bs, log2bs, dataset, idxs, new_xyz, tie_out, tie_iters, prefix_in, t_done_flags);
   }
 }
 
@@ -701,6 +924,49 @@ extern "C" void furthest_point_sampling_chain_kernel_wrapper(int b, int n, int m
                                                              float *temp, int *idxs, float *new_xyz,
                                                              int *tie_out, int tie_iters, const int *prefix_in) {
   fps_dispatch(b, n, m, dataset, temp, idxs, new_xyz, tie_out, tie_iters, prefix_in);
+}
+
+extern "C" int knn_point_slabs(int n);
+extern "C" long long knn_point_build_bytes(int b, int n);
+
+// Level-1 sampler of the fused pipeline: `knn_workspace` / `slab_tab` come from knn_build_kernel_wrapper on the
+// same cloud (the neighbour search of that level needs the build anyway).  Clouds whose slabs fit are sampled by
+// fps_slab_kernel (exact pruning of the distance update), the others by the register-resident kernel, which
+// runs second and skips the clouds flagged in `status` (b ints, device).  Same outputs as the chain wrapper.
+extern "C" void furthest_point_sampling_slab_kernel_wrapper(int b, int n, int m, const float *dataset, int *idxs,
+                                                            float *new_xyz, int *tie_out, int tie_iters,
+                                                            const void *knn_workspace, const int *slab_tab,
+                                                            int *status) {
+  if (b <= 0 || m <= 0) return;
+  PWCLO_REQUIRE(knn_workspace != nullptr && slab_tab != nullptr && status != nullptr,
+                "furthest_point_sampling(slab): workspace, slab table and status buffer are required");
+  const int bs = ref_opt_n_threads(n);
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  const size_t chain_bytes = tie_out ? (size_t)(tie_iters + 2) * 8 : 0;
+  const size_t lds = FPS_SLOT_BYTES + (size_t)n * sizeof(float4) + chain_bytes;
+  PWCLO_REQUIRE(knn_point_slabs(n) == 8 && n >= 4096 && n <= 8 * 18 * 64 && lds <= 160 * 1024,
+                "furthest_point_sampling(slab): n=%d is outside the slab sampler's range (8 slabs, LDS table)", n);
+  (void)dataset;                                          // every point comes from the sorted rows
+  const int nblk = (n + 63) / 64 + 8;
+  const int per = (n + 7) / 8;
+  const char *dbg_e = getenv("PWCLO_FPS_SLAB_DBG");
+  const int dbg = dbg_e ? atoi(dbg_e) : 0;
+  static bool big16 = false, big18 = false;
+#define SLAB_LAUNCH(II, FLAG)                                                                                   \
+  {                                                                                                             \
+    auto kern = fps_slab_kernel<512, II>;                                                                       \
+    if (!FLAG) {                                                                                                \
+      (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
+      FLAG = true;                                                                                              \
+    }                                                                                                           \
+    hipLaunchKernelGGL(kern, dim3(b), dim3(512), lds, current_stream(), n, m, bs, log2bs, nblk,                 \
+                       reinterpret_cast<const float4 *>(knn_workspace), slab_tab, idxs, new_xyz, tie_out,       \
+                       tie_iters, status, dbg);                                                                 \
+  }
+  if (per <= 16 * 64) SLAB_LAUNCH(16, big16) else SLAB_LAUNCH(18, big18)
+#undef SLAB_LAUNCH
+  check_launch("furthest_point_sampling(slab)");
 }
 
 extern "C" void gather_points_kernel_wrapper(int b, int c, int n, int npoints, const float *points,

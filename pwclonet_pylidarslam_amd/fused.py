@@ -225,6 +225,45 @@ def fps_with_xyz(xyz, npoint, tie_out=None, tie_iters=0, prefix_in=None):
     return idx, new_xyz
 
 
+def fps_slab_supported(n):
+    """Level-1 clouds the bucket-pruned sampler takes (csrc/sampling.hip: fps_slab_kernel): 8 x-slabs, LDS table.
+    OPT-IN (PWCLO_FPS_SLAB=1): exact and tested, but measured SLOWER than the register-resident kernel at n = 8192
+    (2.1 ms against 1.82 ms per level-1 call: the ~4 of 128 buckets a new sample touches still cost a serial
+    update -> 16-slot arg-max -> two wave reductions chain, ~1400 cycles, where the unpruned loop's sixteen
+    independent chains take ~1050)."""
+    return (os.environ.get("PWCLO_FPS_SLAB", "0") != "0" and 4096 <= n <= 9216 and _lib.load().knn_point_slabs(n) == 8)
+
+
+def fps_slab_with_xyz(xyz, npoint, tie_out=None, tie_iters=0):
+    """``fps_with_xyz`` for the pyramid's first level: builds the cloud's neighbour-search structure first (the level's
+    knn needs it anyway), samples with the slab-pruned kernel and returns the structure for ``knn_prebuilt``.
+    -> (idx (B,npoint) int32, new_xyz (B,npoint,3), workspace)."""
+    B, N, _ = xyz.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.knn_point_build_bytes(B, N),), dtype=torch.uint8, device=xyz.device)
+    tab = torch.empty((B, 32), dtype=torch.int32, device=xyz.device)
+    status = torch.empty((B,), dtype=torch.int32, device=xyz.device)
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
+    _lib.annotate(family="knn", units=0.0, bytes=4.0 * B * 7 * N)
+    _lib.call("knn_build_kernel_wrapper", xyz.device, B, N, _p(xyz), _p(ws), _p(tab))
+    _lib.annotate(family="fps", units=float(B) * (npoint - 1) * N, iters=npoint - 1,
+                  bytes=4.0 * B * (3 * N + 4 * npoint))
+    _lib.call("furthest_point_sampling_slab_kernel_wrapper", xyz.device, B, N, npoint, _p(xyz), _p(idx), _p(new_xyz),
+              _p(tie_out), int(tie_iters), _p(ws), _p(tab), _p(status))
+    return idx, new_xyz, (ws, tab, status)
+
+
+def knn_prebuilt(nsample, xyz, new_xyz, ws):
+    """knn on a structure built by ``fps_slab_with_xyz`` (same cloud): the search pass alone."""
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
+    _lib.annotate(family="knn", units=float(B) * S * N, bytes=4.0 * B * (3 * N + 3 * S + S * nsample))
+    _lib.call("knn_point_prebuilt_kernel_wrapper", xyz.device, B, N, S, int(nsample), _p(new_xyz), _p(idx), 0, _p(ws[0]))
+    return idx
+
+
 def quat_warp_pm(xyz, q, t):
     """xyz (B,N,3) point-major, q (B,4), t (B,3) -> (B,N,3)."""
     B, N, _ = xyz.shape
@@ -774,10 +813,14 @@ class FusedPWCLONet:
         npoints = [n for n, _ in self.sa_cfg]
         chain = self.fps_chain and all(a >= b_ for a, b_ in zip(npoints, npoints[1:])) and len(npoints) > 1
         flag = torch.empty((x.shape[0], FPS_CHAIN_INTS), dtype=torch.int32, device=x.device) if chain else None
+        ws0 = None
         with br.fork(0):
             src = x
             for lvl, npoint in enumerate(npoints):
-                if chain and lvl == 0:
+                if lvl == 0 and fps_slab_supported(src.shape[1]):
+                    _, src, ws0 = fps_slab_with_xyz(src, npoint, tie_out=flag, tie_iters=npoints[1] if chain else 0)
+                    br.hold(src, *ws0)
+                elif chain and lvl == 0:
                     _, src = br.hold(*fps_with_xyz(src, npoint, tie_out=flag, tie_iters=npoints[1]))
                 elif chain:
                     _, src = br.hold(*fps_with_xyz(src, npoint, prefix_in=flag))
@@ -787,7 +830,7 @@ class FusedPWCLONet:
                 ready.append(br.mark(0))
             if flag is not None:
                 br.hold(flag)
-        return dict(B=B, x=x, samples=samples, ready=ready, br=br)
+        return dict(B=B, x=x, samples=samples, ready=ready, br=br, ws0=ws0)
 
     @torch.no_grad()
     def rest(self, state, return_intermediates=False):
@@ -800,7 +843,10 @@ class FusedPWCLONet:
         for lvl, (fsa, (npoint, nsample)) in enumerate(zip(self.sa, self.sa_cfg)):
             br.wait(ready[lvl])
             new_x = samples[lvl]
-            idx = br.hold(knn(nsample, x, new_x))
+            if lvl == 0 and state.get("ws0") is not None:     # the sampler already built this cloud's search structure
+                idx = br.hold(knn_prebuilt(nsample, x, new_x, state["ws0"]))
+            else:
+                idx = br.hold(knn(nsample, x, new_x))
             if taps is not None:
                 taps["psa_%d.knn_idx" % (lvl + 1)] = idx
             if self.hoist:

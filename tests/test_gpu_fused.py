@@ -481,3 +481,51 @@ def test_bf16_dtype_path_against_fp32_golden(cuda, case):
     assert e13 <= 2e-2, e13
     assert err <= 3e-2 * scale, (err, scale)
     assert not torch.equal(pose, pose32)                     # it really is the other arithmetic
+
+
+def test_fps_slab_pruned_sampler_matches_oracle_and_classic_kernel(cuda):
+    """Level-1 sampler of the fused pipeline (csrc/sampling.hip: fps_slab_kernel): a wave skips its distance update
+    whenever the new sample provably cannot lower a running distance inside its x-slab.  Must be invisible: indices
+    and sampled coordinates equal the oracle's bit for bit on lidar-shaped clouds, an integer lattice (exact ties at
+    every decision), a cloud with zero-padding rows and a cloud whose points pile up in one x-bin (very unequal slabs:
+    the waves take equal RANGES of the sorted rows, not slabs); the sampling-chain record equals the classic
+    kernel's; and the neighbour search on the structure the sampler built equals the oracle's lists."""
+    import bench
+    gen = torch.Generator().manual_seed(5)
+    x1, x2 = bench.make_batch(6, 8192, 1000, torch.device("cpu"))
+    lidar = torch.cat((x1, x2)).permute(0, 2, 1).contiguous()                       # 12 clouds
+    lattice = torch.randint(-12, 13, (1, 8192, 3), generator=gen).float()
+    padded = lidar[:1].clone()
+    padded[0, 5000:] = 0.0                                                          # zero rows: never sampled
+    wall = (torch.rand(1, 8192, 3, generator=gen) * 2 - 1) * 20
+    wall[0, :6000, 0] = 3.0                                                         # 6000 points share one x: one huge slab
+    x = torch.cat((lidar, lattice, padded, wall)).contiguous()
+    B = x.shape[0]
+    ref = O.furthest_point_sampling(x, 2048)
+    rec = torch.full((B, fused.FPS_CHAIN_INTS), -1, dtype=torch.int32, device=cuda)
+    idx, new_xyz, ws = fused.fps_slab_with_xyz(x.to(cuda), 2048, tie_out=rec, tie_iters=1024)
+    assert torch.equal(idx.cpu(), ref)
+    assert torch.equal(new_xyz.cpu(), torch.gather(x, 1, ref.long().unsqueeze(-1).expand(-1, -1, 3)))
+    assert ws[2].cpu().tolist() == [1] * B                                           # every cloud, the wall included
+    rec_c = torch.full((B, fused.FPS_CHAIN_INTS), -1, dtype=torch.int32, device=cuda)
+    idx_c, _ = fused.fps_with_xyz(x.to(cuda), 2048, tie_out=rec_c, tie_iters=1024)
+    assert torch.equal(idx_c, idx)
+    # chain records: the pruned kernel flags a tie only when the GLOBAL maximum is attained twice (the classic kernel
+    # also flags a wave-local duplicate below the maximum, which merely costs a fallback), so on tie-free clouds the
+    # records are equal and everywhere the later levels driven by the record equal the oracle's
+    r, rc = rec.cpu(), rec_c.cpu()
+    for b in list(range(12)) + [13, 14]:                                             # all but the lattice cloud
+        assert torch.equal(r[b, :2], rc[b, :2]), b
+        assert sorted(r[b, 2:2 + int(r[b, 1])].tolist()) == sorted(rc[b, 2:2 + int(rc[b, 1])].tolist()), b
+    assert (r[:, 0] <= rc[:, 0]).all()                                               # never more fallbacks than the classic kernel
+    i1, s1 = fused.fps_with_xyz(new_xyz, 1024, prefix_in=rec)
+    assert torch.equal(i1.cpu(), O.furthest_point_sampling(new_xyz.cpu().contiguous(), 1024))
+    i2, _ = fused.fps_with_xyz(s1, 256, prefix_in=rec)
+    assert torch.equal(i2.cpu(), O.furthest_point_sampling(s1.cpu().contiguous(), 256))
+    # the structure it built serves the level's neighbour search
+    got = fused.knn_prebuilt(32, x.to(cuda), new_xyz, ws).cpu()
+    want = O.knn_point_with_dist(32, x[:3].contiguous(), new_xyz[:3].cpu().contiguous())[1]
+    assert torch.equal(got[:3], want)
+    # without a chain record
+    idx2, _, _ = fused.fps_slab_with_xyz(x[:2].contiguous().to(cuda), 700)
+    assert torch.equal(idx2.cpu(), ref[:2, :700])

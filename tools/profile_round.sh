@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the profile artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh v17      -> gpurun_out/prof_v17/*  (copy the summaries into profiles/rNN/ afterwards)
+#   tools/profile_round.sh r02_v1      -> gpurun_out/prof_r02_v1/*  (copy the summaries into profiles/rNN/ afterwards)
 # rocprofv3 gets the python interpreter directly after `--` (no wrapper hop); PMC counters in separate passes.
 set -eo pipefail
 tag=${1:-vXX}
@@ -10,18 +10,24 @@ mkdir -p $out
 trap 'find $out -name "*.db" -delete; find $out -name "*kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete; find $out -name "*agent_info.csv" -delete' EXIT
 export TMPDIR=/tmp
 python bench.py > $out/${tag}_default_bench.json
+python bench.py --config 5 > $out/${tag}_config5_bench.json
+python bench.py --batch 1 --no-cpu-baseline --no-variants > $out/${tag}_config2_batch1_bench.json
 python tools/launch_table.py > $out/${tag}_launch_table.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/default -o default -- python bench.py --no-cpu-baseline --no-variants > $out/${tag}_default_bench_under_rocprof.json 2> $out/rocprof_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/eager -o eager -- python bench.py --launch eager --inflight 1 --no-cpu-baseline --no-variants > $out/${tag}_eager_inflight1_under_rocprof.json 2> $out/rocprof_eager.err
+python tools/wgtrace.py > $out/${tag}_wgtrace_inflight4.txt 2>&1
+python tools/wgtrace.py --ablate knn > $out/${tag}_wgtrace_noknn.txt 2>&1
+python tools/wgtrace.py --ablate fps,knn > $out/${tag}_wgtrace_mlp_only.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/default -o default -- python bench.py --no-cpu-baseline --no-variants --repeats 3 > $out/${tag}_default_bench_under_rocprof.json 2> $out/rocprof_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/eager -o eager -- python bench.py --launch eager --inflight 1 --no-cpu-baseline --no-variants --repeats 3 > $out/${tag}_eager_inflight1_under_rocprof.json 2> $out/rocprof_eager.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5 -o c5 -- python bench.py --config 5 --no-cpu-baseline > $out/${tag}_config5_under_rocprof.json 2> $out/rocprof_c5.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
 find $out -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | sort
 cp "$(find $out/default -name '*kernel_stats.csv' | head -1)" $out/${tag}_default_bench_kernel_stats.csv
 cp "$(find $out/eager -name '*kernel_stats.csv' | head -1)" $out/${tag}_eager_inflight1_kernel_stats.csv
+cp "$(find $out/c5 -name '*kernel_stats.csv' | head -1)" $out/${tag}_config5_kernel_stats.csv
 python tools/pmc_traffic.py "$(find $out/fetch -name '*counter_collection.csv' | head -1)" \
        "$(find $out/write -name '*counter_collection.csv' | head -1)" -o $out/pmc_traffic.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out/sq -o sq -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
 python tools/pmc_mfma.py "$(find $out/sq -name '*counter_collection.csv' | head -1)" -o $out/pmc_mfma_busy.json > $out/pmc_mfma_busy.txt
-tail -c 400 $out/${tag}_default_bench_under_rocprof.json; echo
-tail -c 400 $out/${tag}_eager_inflight1_under_rocprof.json; echo
+tail -c 300 $out/${tag}_default_bench_under_rocprof.json; echo
 ls -la $out
