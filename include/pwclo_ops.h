@@ -142,6 +142,14 @@ int knn_point_slabs(int n);
 void knn_build_kernel_wrapper(int b, int n, const float *xyz, void *workspace, int *slab_tab);
 void knn_point_prebuilt_kernel_wrapper(int b, int n, int s, int nsample, const float *new_xyz, int *idx, float *dist,
                                        void *workspace);
+/* Large clouds (n > 24576) presented in a spatially coherent order: sorted (b,n,3) = dataset gathered by perm (b,n),
+ * perm[p] = original index of sorted position p; inside every block of 1024 consecutive positions the positions are
+ * ordered by ascending sampling priority (bitrev(k mod bs) << 23 | k div bs of the original index k).  A wave of the
+ * cooperative sampler then owns a compact cell and skips its distance update -- exactly -- whenever the new sample is
+ * farther from the cell's box than the largest running distance.  Same idxs (ORIGINAL numbering) / new_xyz as
+ * furthest_point_sampling_xyz_kernel_wrapper, bit for bit.  temp: the (b,n) scratch, 8-byte aligned. */
+void furthest_point_sampling_sorted_kernel_wrapper(int b, int n, int m, const float *dataset, const float *sorted,
+                                                   const int *perm, float *temp, int *idxs, float *new_xyz);
 /* furthest_point_sampling_chain_kernel_wrapper for a cloud whose search structure exists (knn_point_slabs(n) == 8,
  * n >= 4096: level 1 of the pyramid): the distance update of a wave is skipped, exactly, whenever the new sample
  * cannot lower any running distance inside the wave's x-slab (csrc/sampling.hip: fps_slab_kernel).  status: b ints

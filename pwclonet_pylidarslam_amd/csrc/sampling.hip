@@ -589,13 +589,25 @@ __device__ __forceinline__ void coop_post(unsigned long long *w, unsigned payloa
 // stop too), posts PWCLO_ECOOP_TIMEOUT into the library's pinned error word `host_err` (state.hip) and ends.
 // `holdback` (debug, PWCLO_FPS_COOP_DEBUG_TIMEOUT=1): the last workgroup of every cloud exits at once, which
 // is what a non-resident peer looks like to the others -- used by the test of the failure path.
-template <int I>
+// SORTED (furthest_point_sampling_sorted_kernel_wrapper): `dataset` is the cloud in a spatially coherent order and
+// `perm` gives every position's ORIGINAL index.  A wave then owns I * 64 consecutive positions = a compact cell, and
+// its whole distance update is skipped -- exactly -- whenever the new sample is at least as far from the cell's
+// bounding box as the largest running distance anywhere (the previous winner's value): every point of the cell has
+// d >= that box distance in fp32 as well (monotone rounding, same expression), so min(d, running) = running and the
+// lanes' cached candidates stay valid.  Within a cell the host orders positions by priority, which keeps the
+// strict `>` of the per-lane scan equivalent to the reference's tie rule; priorities come from the original index
+// (LDS table), so the output is the unsorted kernel's, bit for bit.  At n ~ 1e5 a sample touches a handful of the
+// ~100 cells: the update leaves the critical path of most SIMDs.
+template <int I, bool SORTED>
 __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, int log2bs, int G,
                                                           const float *__restrict__ dataset,
                                                           unsigned long long *__restrict__ ws,
                                                           int *__restrict__ idxs,
                                                           float *__restrict__ new_xyz, int spin_limit,
-                                                          int holdback, unsigned *host_err) {
+                                                          int holdback, unsigned *host_err,
+                                                          const int *__restrict__ perm,
+                                                          const float *__restrict__ orig_dataset) {
+  extern __shared__ __attribute__((aligned(16))) unsigned pri_lds[];   // SORTED: [I][COOP_T] priorities
   __shared__ unsigned long long slots[3];
   __shared__ unsigned long long bcast;      // winning key, ~0 = timed out
   __shared__ float bxyz[3];                 // its coordinates
@@ -611,16 +623,41 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
 
   float x[I], y[I], z[I];
   int td[I];
+  const float INF_ = __int_as_float(0x7f800000);
+  float lox = INF_, loy = INF_, loz = INF_, hix = -INF_, hiy = -INF_, hiz = -INF_;   // SORTED: this wave's box
+  const int *permc = SORTED ? perm + (size_t)cloud * n : nullptr;
 #pragma unroll
   for (int i = 0; i < I; ++i) {
-    const int k = vtid + ttotal * i;
+    // unsorted: residue classes of the reference's thread partition; sorted: I * 64 consecutive positions per wave
+    const int k = SORTED ? ((g * (COOP_T / 64) + (tid >> 6)) * I + i) * 64 + lane : vtid + ttotal * i;
     float px = 0.f, py = 0.f, pz = 0.f, t0 = -1.0f;
+    unsigned pr = 0xFFFFFFFFu;
     if (k < n) {
       px = pts[(size_t)k * 3 + 0]; py = pts[(size_t)k * 3 + 1]; pz = pts[(size_t)k * 3 + 2];
       const float mag = (px * px) + (py * py) + (pz * pz);
-      if (!((double)mag <= 1e-3)) t0 = 1e10f;
+      if (!((double)mag <= 1e-3)) {
+        t0 = 1e10f;
+        if (SORTED) {
+          lox = fminf(lox, px); hix = fmaxf(hix, px);
+          loy = fminf(loy, py); hiy = fmaxf(hiy, py);
+          loz = fminf(loz, pz); hiz = fmaxf(hiz, pz);
+        }
+      }
+      if (SORTED) {
+        const unsigned o = (unsigned)permc[k];
+        pr = (fps_bitrev(o & (unsigned)(bs - 1), log2bs) << PRI_SHIFT) | (o >> log2bs);
+      }
     }
+    if (SORTED) pri_lds[i * COOP_T + tid] = pr;
     x[i] = px; y[i] = py; z[i] = pz; td[i] = __float_as_int(t0);
+  }
+  if (SORTED) {
+    lox = wave_allreduce_f32(lox, [](float a, float b) { return fminf(a, b); });
+    loy = wave_allreduce_f32(loy, [](float a, float b) { return fminf(a, b); });
+    loz = wave_allreduce_f32(loz, [](float a, float b) { return fminf(a, b); });
+    hix = wave_allreduce_f32(hix, [](float a, float b) { return fmaxf(a, b); });
+    hiy = wave_allreduce_f32(hiy, [](float a, float b) { return fmaxf(a, b); });
+    hiz = wave_allreduce_f32(hiz, [](float a, float b) { return fmaxf(a, b); });
   }
   const unsigned pri_base = (fps_bitrev((unsigned)(vtid & (bs - 1)), log2bs) << PRI_SHIFT) | (unsigned)(vtid / bs);
   const unsigned qstep = (unsigned)(ttotal / bs);
@@ -628,28 +665,45 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
     slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull;
     if (g == 0) out[0] = 0;
   }
-  float x1 = pts[0], y1 = pts[1], z1 = pts[2];     // sample 0 is point 0
+  // sample 0 is ORIGINAL point 0 (in sorted mode pts[0] is some other point)
+  const float *first = SORTED ? orig_dataset + (size_t)cloud * n * 3 : pts;
+  float x1 = first[0], y1 = first[1], z1 = first[2];
   if (oxyz && g == 0 && tid == 0) { oxyz[0] = x1; oxyz[1] = y1; oxyz[2] = z1; }
   __syncthreads();
 
   bool failed = false;
+  // SORTED: the lane's candidate and the wave's arg-max persist across iterations whose update is skipped
+  int bestj = 0;
+  unsigned mine = 0u, wmax = 0u, wpri = 0xFFFFFFFFu, mypri = 0xFFFFFFFFu;
+  unsigned gmax = 0x7FFFFFFFu;            // bits + 1 of the previous winner's distance: bounds every running distance
   for (int it = 1; it < m && !failed; ++it) {
-    int best = __float_as_int(-1.0f), bestj = 0;
-#pragma unroll
-    for (int j = 0; j < I; ++j) {
-      const float dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1;
-      const float d = dx * dx + dy * dy + dz * dz;
-      const int d2 = min(__float_as_int(d), td[j]);
-      td[j] = d2;
-      const bool better = d2 > best;
-      bestj = better ? j : bestj;
-      best = better ? d2 : best;
+    bool active = true;
+    if (SORTED) {
+      const float gx = fmaxf(fmaxf(lox - x1, x1 - hix), 0.f);
+      const float gy = fmaxf(fmaxf(loy - y1, y1 - hiy), 0.f);
+      const float gz = fmaxf(fmaxf(loz - z1, z1 - hiz), 0.f);
+      const float bd = gx * gx + gy * gy + gz * gz;            // the update's own expression on the box gap
+      active = __builtin_amdgcn_readfirstlane((int)((unsigned)__float_as_int(bd) + 1u < gmax)) != 0;
     }
-    const unsigned mine = best < 0 ? 0u : (unsigned)best + 1u;
-    const unsigned wmax = wave_reduce_u32(mine, OpMaxU32());
-    const unsigned mypri = pri_base + qstep * (unsigned)bestj;
-    const unsigned cand = (mine == wmax && mine != 0u) ? mypri : 0xFFFFFFFFu;
-    const unsigned wpri = wave_reduce_u32(cand, OpMinU32());
+    if (active) {
+      int best = __float_as_int(-1.0f);
+      bestj = 0;
+#pragma unroll
+      for (int j = 0; j < I; ++j) {
+        const float dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const int d2 = min(__float_as_int(d), td[j]);
+        td[j] = d2;
+        const bool better = d2 > best;
+        bestj = better ? j : bestj;
+        best = better ? d2 : best;
+      }
+      mine = best < 0 ? 0u : (unsigned)best + 1u;
+      wmax = wave_reduce_u32(mine, OpMaxU32());
+      mypri = SORTED ? pri_lds[bestj * COOP_T + tid] : pri_base + qstep * (unsigned)bestj;
+      const unsigned cand = (mine == wmax && mine != 0u) ? mypri : 0xFFFFFFFFu;
+      wpri = wave_reduce_u32(cand, OpMinU32());
+    }
     const unsigned long long key =
         wmax == 0u ? 0ull : (((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wpri));
     unsigned long long *slot = slots + (it % 3);
@@ -722,12 +776,13 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
     if (kmax == ~0ull) {
       failed = true;
     } else if (kmax == 0ull) {       // nothing left to sample anywhere: index 0 again, like the reference
-      x1 = pts[0]; y1 = pts[1]; z1 = pts[2];
+      x1 = first[0]; y1 = first[1]; z1 = first[2];
     } else {
       const unsigned p = 0xFFFFFFFFu - (unsigned)(kmax & 0xFFFFFFFFull);
       old = (int)fps_bitrev(p >> PRI_SHIFT, log2bs) + bs * (int)(p & ((1u << PRI_SHIFT) - 1u));
       x1 = bxyz[0]; y1 = bxyz[1]; z1 = bxyz[2];
     }
+    gmax = failed ? 0u : (unsigned)(kmax >> 32);
     if (g == 0 && tid == 0 && !failed) {
       out[it] = old;
       if (oxyz) { oxyz[it * 3 + 0] = x1; oxyz[it * 3 + 1] = y1; oxyz[it * 3 + 2] = z1; }
@@ -810,6 +865,66 @@ using namespace pwclo;
 extern "C" void group_points_grad_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
                                                  const float *grad_out, const int *idx, float *grad_points);
 
+// Launch of the cooperative sampler (both orders).  All G workgroups of a cloud must be resident together:
+// hipLaunchCooperativeKernel makes the runtime guarantee exactly that (the launch is REJECTED if the grid cannot be
+// co-resident, and the grid is dispatched as a whole even when other streams hold CUs); a stream under graph capture
+// cannot take a cooperative launch, there the plain launch with the 224-workgroup cap is used and the bounded
+// spins + error word are the safety net.  PWCLO_FPS_COOP_LAUNCH=0 forces the plain launch.
+static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const float *dataset,
+                        unsigned long long *ws, int *idxs, float *new_xyz, const int *perm,
+                        const float *orig_dataset) {
+  hipStream_t st = current_stream();
+  unsigned *host_err = device_error_word();            // a timeout inside the kernel reaches pwclo_last_error()
+  if (host_err == nullptr) return;
+  const char *dbg = getenv("PWCLO_FPS_COOP_DEBUG_TIMEOUT");   // test hook of the failure path (read per call)
+  int holdback = dbg ? atoi(dbg) : 0;
+  int spin_limit = holdback ? 256 : (1 << 21);
+  hipLaunchKernelGGL(fps_coop_init_kernel, dim3(ceil_div(b * COOP_WS_WORDS, 256)), dim3(256), 0, st, ws,
+                     b * COOP_WS_WORDS);
+  static int coop_api = -1;
+  if (coop_api < 0) { const char *e = getenv("PWCLO_FPS_COOP_LAUNCH"); coop_api = e ? atoi(e) : 1; }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  const bool use_coop_api = coop_api && cap == hipStreamCaptureStatusNone;
+  const bool sorted = perm != nullptr;
+  const size_t lds = sorted ? (size_t)16 * COOP_T * sizeof(unsigned) : 0;
+  const void *kern = sorted ? reinterpret_cast<const void *>(fps_coop_kernel<16, true>)
+                            : reinterpret_cast<const void *>(fps_coop_kernel<16, false>);
+  static bool lds_attr = false;
+  if (sorted && !lds_attr) {
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_attr = true;
+  }
+  const int per_launch = 224 / G;
+  for (int c0 = 0; c0 < b; c0 += per_launch) {
+    const int nb = min(per_launch, b - c0);
+    const float *d0 = dataset + (size_t)c0 * n * 3;
+    unsigned long long *w0 = ws + (size_t)c0 * COOP_WS_WORDS;
+    int *i0 = idxs + (size_t)c0 * m;
+    float *x0 = new_xyz ? new_xyz + (size_t)c0 * m * 3 : nullptr;
+    const int *p0 = sorted ? perm + (size_t)c0 * n : nullptr;
+    const float *o0 = sorted ? orig_dataset + (size_t)c0 * n * 3 : nullptr;
+    if (use_coop_api) {
+      int nv = n, mv = m, bsv = bs, lbv = log2bs, Gv = G;
+      void *args[] = {&nv, &mv, &bsv, &lbv, &Gv, &d0, &w0, &i0, &x0, &spin_limit, &holdback, &host_err, &p0, &o0};
+      hipError_t e = hipLaunchCooperativeKernel(kern, dim3(G, nb), dim3(COOP_T), args, (unsigned)lds, st);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error((int)e, "furthest_point_sampling(coop): cooperative launch of %d x %d workgroups rejected: %s",
+                  G, nb, hipGetErrorString(e));
+        return;
+      }
+    } else if (sorted) {
+      hipLaunchKernelGGL((fps_coop_kernel<16, true>), dim3(G, nb), dim3(COOP_T), lds, st, n, m, bs, log2bs, G, d0, w0,
+                         i0, x0, spin_limit, holdback, host_err, p0, o0);
+    } else {
+      hipLaunchKernelGGL((fps_coop_kernel<16, false>), dim3(G, nb), dim3(COOP_T), 0, st, n, m, bs, log2bs, G, d0, w0,
+                         i0, x0, spin_limit, holdback, host_err, p0, o0);
+    }
+  }
+  check_launch("furthest_point_sampling(coop)");
+}
+
 static void fps_dispatch(int b, int n, int m, const float *dataset, float *temp, int *idxs,
                          float *new_xyz, int *tie_out = nullptr, int tie_iters = 0,
                          const int *prefix_in = nullptr) {
@@ -860,49 +975,8 @@ static void fps_dispatch(int b, int n, int m, const float *dataset, float *temp,
   // (8 points per thread on twice the workgroups was measured slower: 3.2 vs 2.9 us per iteration at n = 120k)
   if (coop && G <= COOP_MAX_G && (reinterpret_cast<uintptr_t>(temp) & 7) == 0 && (size_t)COOP_WS_WORDS * 2 <= (size_t)n) {
     // cooperative multi-workgroup sampler; `temp` doubles as its (re-zeroed) exchange workspace
-    unsigned long long *ws = reinterpret_cast<unsigned long long *>(temp);
-    hipStream_t st = current_stream();
-    unsigned *host_err = device_error_word();            // a timeout inside the kernel reaches pwclo_last_error()
-    if (host_err == nullptr) return;
-    const char *dbg = getenv("PWCLO_FPS_COOP_DEBUG_TIMEOUT");   // test hook of the failure path (read per call)
-    int holdback = dbg ? atoi(dbg) : 0;
-    int spin_limit = holdback ? 256 : (1 << 21);
-    hipLaunchKernelGGL(fps_coop_init_kernel, dim3(ceil_div(b * COOP_WS_WORDS, 256)), dim3(256), 0, st, ws,
-                       b * COOP_WS_WORDS);
-    // All G workgroups of a cloud must be resident together.  hipLaunchCooperativeKernel makes the runtime
-    // guarantee exactly that (the launch is REJECTED if the grid cannot be co-resident, and the grid is
-    // dispatched as a whole even when other streams hold CUs); a stream under graph capture cannot take a
-    // cooperative launch, there the plain launch with the 224-workgroup cap is used and the bounded spins +
-    // error word are the safety net.  PWCLO_FPS_COOP_LAUNCH=0 forces the plain launch.
-    static int coop_launch = -1;
-    if (coop_launch < 0) { const char *e = getenv("PWCLO_FPS_COOP_LAUNCH"); coop_launch = e ? atoi(e) : 1; }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(st, &cap);
-    const bool use_coop_api = coop_launch && cap == hipStreamCaptureStatusNone;
-    const int per_launch = 224 / G;
-    for (int c0 = 0; c0 < b; c0 += per_launch) {
-      const int nb = min(per_launch, b - c0);
-      const float *d0 = dataset + (size_t)c0 * n * 3;
-      unsigned long long *w0 = ws + (size_t)c0 * COOP_WS_WORDS;
-      int *i0 = idxs + (size_t)c0 * m;
-      float *x0 = new_xyz ? new_xyz + (size_t)c0 * m * 3 : nullptr;
-      if (use_coop_api) {
-        int nv = n, mv = m, bsv = bs, lbv = log2bs, Gv = G;
-        void *args[] = {&nv, &mv, &bsv, &lbv, &Gv, &d0, &w0, &i0, &x0, &spin_limit, &holdback, &host_err};
-        hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(fps_coop_kernel<16>), dim3(G, nb),
-                                                  dim3(COOP_T), args, 0, st);
-        if (e != hipSuccess) {
-          (void)hipGetLastError();
-          set_error((int)e, "furthest_point_sampling(coop): cooperative launch of %d x %d workgroups rejected: %s",
-                    G, nb, hipGetErrorString(e));
-          return;
-        }
-      } else {
-        hipLaunchKernelGGL((fps_coop_kernel<16>), dim3(G, nb), dim3(COOP_T), 0, st, n, m, bs, log2bs, G, d0, w0, i0,
-                           x0, spin_limit, holdback, host_err);
-      }
-    }
-    check_launch("furthest_point_sampling(coop)");
+    coop_launch(b, n, m, bs, log2bs, G, dataset, reinterpret_cast<unsigned long long *>(temp), idxs, new_xyz,
+                nullptr, nullptr);
     return;
   }
   hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, current_stream(), n, m, bs,
@@ -924,6 +998,28 @@ extern "C" void furthest_point_sampling_chain_kernel_wrapper(int b, int n, int m
                                                              float *temp, int *idxs, float *new_xyz,
                                                              int *tie_out, int tie_iters, const int *prefix_in) {
   fps_dispatch(b, n, m, dataset, temp, idxs, new_xyz, tie_out, tie_iters, prefix_in);
+}
+
+// Large clouds (n > 24576) in a spatially coherent order: `sorted` (b,n,3) = `dataset` gathered by `perm` (b,n), perm[p] =
+// original index of sorted position p; inside every block of 1024 consecutive positions the positions must be
+// ordered by ascending sampling priority (pointnet2_ops/_ext.py builds both with torch sorts).  Same indices
+// (ORIGINAL numbering) and coordinates as furthest_point_sampling_xyz_kernel_wrapper, bit for bit; the distance
+// update of a wave is skipped whenever the new sample cannot lower any running distance in its cell.
+extern "C" void furthest_point_sampling_sorted_kernel_wrapper(int b, int n, int m, const float *dataset,
+                                                              const float *sorted, const int *perm, float *temp,
+                                                              int *idxs, float *new_xyz) {
+  if (b <= 0 || m <= 0) return;
+  PWCLO_REQUIRE(n > 24576 && (long long)n < (1ll << PRI_SHIFT), "furthest_point_sampling(sorted): n=%d outside (24576, 2^23)", n);
+  PWCLO_REQUIRE(dataset != nullptr && sorted != nullptr && perm != nullptr && temp != nullptr,
+                "furthest_point_sampling(sorted): dataset, sorted copy, permutation and temp are required");
+  const int bs = ref_opt_n_threads(n);
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  const int G = ceil_div(n, COOP_T * 16);
+  PWCLO_REQUIRE(G <= COOP_MAX_G && (reinterpret_cast<uintptr_t>(temp) & 7) == 0 && (size_t)COOP_WS_WORDS * 2 <= (size_t)n,
+                "furthest_point_sampling(sorted): n=%d needs %d workgroups per cloud (max %d) / an 8-byte aligned temp", n, G,
+                COOP_MAX_G);
+  coop_launch(b, n, m, bs, log2bs, G, sorted, reinterpret_cast<unsigned long long *>(temp), idxs, new_xyz, perm, dataset);
 }
 
 extern "C" int knn_point_slabs(int n);

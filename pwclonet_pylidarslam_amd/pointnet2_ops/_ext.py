@@ -10,6 +10,8 @@ ops of the same path that get native kernels here: ``knn_point`` and ``quat_warp
 Unlike the reference there is no JIT fallback and no silent path: every function launches a
 HIP kernel through the C ABI or raises.
 """
+import os as _os
+
 import torch
 
 from .. import _lib
@@ -60,18 +62,68 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
+_PRI_TABLES = {}
+
+
+def _fps_priorities(n, device):
+    """Sampling priority of every ORIGINAL index of an n-point cloud (csrc/sampling.hip: the reference's thread
+    partition + tie-keeping tree order ties by (bitrev(k mod bs), k div bs), bs = 2^floor(log2 n) <= 512)."""
+    key = (n, str(device))
+    if key not in _PRI_TABLES:
+        bs = 1
+        while bs * 2 <= n and bs < 512:
+            bs *= 2
+        bits = bs.bit_length() - 1
+        rev = torch.tensor([int(format(r, "0%db" % bits)[::-1], 2) if bits else 0 for r in range(bs)], dtype=torch.int64)
+        k = torch.arange(n, dtype=torch.int64)
+        _PRI_TABLES[key] = ((rev[k % bs] << 23) | (k // bs)).to(device)
+    return _PRI_TABLES[key]
+
+
+def _fps_sorted_order(points):
+    """Spatially coherent order for the large-cloud sampler: Morton order of the coordinates (10 bits per axis, per-cloud
+    box), cut into cells of 1024 consecutive positions, each cell ordered by ascending sampling priority.
+    points (B,N,3) -> (sorted (B,N,3) f32, perm (B,N) i32: original index of every sorted position).  Torch sorts:
+    plumbing around the kernel, ~0.3 ms for 16 clouds of 1e5 points against the 8 ms the pruned update saves."""
+    B, N, _ = points.shape
+    lo = points.amin(dim=1, keepdim=True)
+    span = (points.amax(dim=1, keepdim=True) - lo).clamp_min(1e-20)
+    q = ((points - lo) * (1023.0 / span)).to(torch.int64).clamp_(0, 1023)
+
+    def spread(v):                                  # 10 bits -> bits 0, 3, 6, ...
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+    code = spread(q[..., 0]) | (spread(q[..., 1]) << 1) | (spread(q[..., 2]) << 2)
+    order = torch.argsort(code, dim=1)
+    rank = torch.empty_like(order)
+    rank.scatter_(1, order, torch.arange(N, device=points.device).unsqueeze(0).expand(B, -1))
+    key = ((rank // 1024) << 32) | _fps_priorities(N, points.device).unsqueeze(0)
+    perm = torch.argsort(key, dim=1)
+    sorted_pts = torch.gather(points, 1, perm.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    return sorted_pts, perm.to(torch.int32).contiguous()
+
+
 def furthest_point_sampling(points, nsamples):
     """sampling.cpp:66-87.  (B,N,3) f32 -> (B,nsamples) i32.  The reference's (B,N) `tmp` scratch
-    is only allocated when the cloud is too large for the register-resident kernel."""
+    is only allocated when the cloud is too large for the register-resident kernel; those clouds (N > 24576) are
+    also brought into a spatially coherent order first, which lets the cooperative sampler skip -- exactly -- the
+    distance update of every wave whose cell the new sample cannot reach (PWCLO_FPS_SORTED=0: plain order)."""
     _float(points, "points"); _gpu(points)
     B, N, _ = points.shape
     out = torch.zeros((B, nsamples), dtype=torch.int32, device=points.device)
-    tmp = 0
     if N > 24576:
         tmp_t = torch.full((B, N), 1e10, dtype=torch.float32, device=points.device)
-        tmp = _p(tmp_t)
-    _lib.call("furthest_point_sampling_kernel_wrapper", points.device, B, N, nsamples, _p(points), tmp,
-              _p(out))
+        if _os.environ.get("PWCLO_FPS_SORTED", "1") != "0" and N >= 2 * 1024 * 16:
+            sorted_pts, perm = _fps_sorted_order(points)
+            _lib.call("furthest_point_sampling_sorted_kernel_wrapper", points.device, B, N, nsamples, _p(points),
+                      _p(sorted_pts), _p(perm), _p(tmp_t), _p(out), 0)
+            return out
+        _lib.call("furthest_point_sampling_kernel_wrapper", points.device, B, N, nsamples, _p(points), _p(tmp_t),
+                  _p(out))
+        return out
+    _lib.call("furthest_point_sampling_kernel_wrapper", points.device, B, N, nsamples, _p(points), 0, _p(out))
     return out
 
 
@@ -160,7 +212,6 @@ def scatter_grad_deterministic(grad_out, idx, n):
 
 # ---- native replacements of pure-PyTorch ops (include/pwclo_ops.h section 2) ---------------------
 
-import os as _os
 _KNN_MIN_S = int(_os.environ.get("PWCLO_KNN_MIN_S", "256"))     # fewer queries: the exhaustive kernel (no build pass)
 
 

@@ -18,13 +18,14 @@ python tools/wgtrace.py --ablate knn > $out/${tag}_wgtrace_noknn.txt 2>&1
 python tools/wgtrace.py --ablate fps,knn > $out/${tag}_wgtrace_mlp_only.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/default -o default -- python bench.py --no-cpu-baseline --no-variants --repeats 3 > $out/${tag}_default_bench_under_rocprof.json 2> $out/rocprof_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/eager -o eager -- python bench.py --launch eager --inflight 1 --no-cpu-baseline --no-variants --repeats 3 > $out/${tag}_eager_inflight1_under_rocprof.json 2> $out/rocprof_eager.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5 -o c5 -- python bench.py --config 5 --no-cpu-baseline > $out/${tag}_config5_under_rocprof.json 2> $out/rocprof_c5.err
+# config 5 under the profiler: plain launch of the large-cloud sampler (rocprofv3 segfaults on the cooperative-launch API)
+PWCLO_FPS_COOP_LAUNCH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5 -o c5 -- python bench.py --config 5 --no-cpu-baseline > $out/${tag}_config5_under_rocprof.json 2> $out/rocprof_c5.err || echo "config-5 rocprof pass failed (see rocprof_c5.err)"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
 find $out -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | sort
 cp "$(find $out/default -name '*kernel_stats.csv' | head -1)" $out/${tag}_default_bench_kernel_stats.csv
 cp "$(find $out/eager -name '*kernel_stats.csv' | head -1)" $out/${tag}_eager_inflight1_kernel_stats.csv
-cp "$(find $out/c5 -name '*kernel_stats.csv' | head -1)" $out/${tag}_config5_kernel_stats.csv
+cp "$(find $out/c5 -name '*kernel_stats.csv' | head -1)" $out/${tag}_config5_kernel_stats.csv || true
 python tools/pmc_traffic.py "$(find $out/fetch -name '*counter_collection.csv' | head -1)" \
        "$(find $out/write -name '*counter_collection.csv' | head -1)" -o $out/pmc_traffic.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out/sq -o sq -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
