@@ -325,8 +325,10 @@ void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int *cin, cons
 /* sa_fused with pre (b,n,c1) = W1_feat . feat + b1 (NULL at level 0, where layer 1 is whole). */
 void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, int c2, int c3, const float *xyz,
                                const float *new_xyz, const float *pre, const int *idx,
-                               const float *packed_w, float *out, int wfmt, int packed_floats);
-/* upconv_fused with pre (b,n,128) = W1_feat . feat1 + b1. */
+                               const float *packed_w, float *out, int wfmt, int packed_floats, int kmajor);
+/* (kmajor = 1: level-0 stack whose 8-channel layers are packed "k-step major" -- layers 2 and 3 then issue only the two
+ *  MFMA k-steps that carry data; fused.py: pack_layer(kmajor_out=True).)
+ * upconv_fused with pre (b,n,128) = W1_feat . feat1 + b1. */
 void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz2, const float *xyz1,
                                    const float *pre, const int *idx, const float *packed_w, float *out,
                                    int wfmt, int packed_floats);

@@ -116,7 +116,9 @@ struct SAHArgs {
   int B, N, S, K;
 };
 
-template <int B1, int B2, int B3, int KP, int P, int W, bool XYZ_ONLY, int FMT = 0>
+// KMAJ (level 0 only): layers 1 and 2 produce their <= 8 real channels "k-step major" (fused.py: pack_layer
+// kmajor_out), so layers 2 and 3 run only the two k-steps that carry data.
+template <int B1, int B2, int B3, int KP, int P, int W, bool XYZ_ONLY, int FMT = 0, bool KMAJ = false>
 __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
   TraceScope trace_scope_(TK_SA_H);
   constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<FMT>(B1, B2), W3 = layer_floats_any<FMT>(B2, B3);
@@ -159,8 +161,13 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
         for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
       mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
     }
-    mlp_layer_any<FMT, B1, B2, P, true>(h2, h1, lds_w + W1, lane);
-    mlp_layer_any<FMT, B2, B3, P, false>(h3, h2, lds_w + W1 + W2, lane);   // its ReLU is applied after the pool
+    if constexpr (KMAJ) {
+      mlp_layer<B1, B2, P, true, 2>(h2, h1, lds_w + W1, lane);
+      mlp_layer<B2, B3, P, false, 2>(h3, h2, lds_w + W1 + W2, lane);
+    } else {
+      mlp_layer_any<FMT, B1, B2, P, true>(h2, h1, lds_w + W1, lane);
+      mlp_layer_any<FMT, B2, B3, P, false>(h3, h2, lds_w + W1 + W2, lane);   // its ReLU is applied after the pool
+    }
     constexpr int GROUP = KP < 16 ? KP : 16;
     constexpr int BPQ = KP > 16 ? KP / 16 : 1;
 #pragma unroll
@@ -481,9 +488,12 @@ extern "C" void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int
 
 extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, int c2, int c3, const float *xyz,
                                           const float *new_xyz, const float *pre, const int *idx,
-                                          const float *packed_w, float *out, int wfmt, int packed_floats) {
+                                          const float *packed_w, float *out, int wfmt, int packed_floats,
+                                          int kmajor) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(k >= 1 && k <= 32, "sa_fused_h: nsample=%d outside [1,32]", k);
+  PWCLO_REQUIRE(kmajor == 0 || (pre == nullptr && c1 == 16 && c2 == 16 && c3 == 16),
+                "sa_fused_h: the k-step-major layout exists for the level-0 stack (16,16,16 without features) only");
   PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 32)), "sa_fused_h: batch too large for 32-bit offsets (b=%d)", b);
   SAHArgs a{xyz, new_xyz, pre, idx, packed_w, out, b, n, s, k};
   const int kp = k > 16 ? 32 : 16;
@@ -509,6 +519,16 @@ extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, in
       launch_h<WW>(sa_h_kernel<A1 / 16, A2 / 16, A3 / 16, KP, PP, WW, XYZ>, attr, lds, tiles_h(b, s, KP, PP), a); \
     check_launch("sa_fused_h");                                                                       \
     return;                                                                                           \
+  }
+  if (kmajor) {                               // psa_1 with 8-channel layers packed k-step major (fp32 tiles only)
+    static bool attrk = false;
+    constexpr int ldsk = 4 * (layer_floats(1, 1) + layer_floats(1, 1) + layer_floats(1, 1));
+    PWCLO_REQUIRE(packed_floats == ldsk / 4, "sa_fused_h: packed weights hold %d floats, the level-0 stack needs %d",
+                  packed_floats, ldsk / 4);
+    PWCLO_REQUIRE(kp == 32, "sa_fused_h: the level-0 stack is built for nsample in (16, 32] (got %d)", k);
+    launch_h<8>(sa_h_kernel<1, 1, 1, 32, 2, 8, true, 0, true>, attrk, ldsk, tiles_h(b, s, 32, 2), a);
+    check_launch("sa_fused_h");
+    return;
   }
   SAH_CASE(16, 16, 16, 32, true, 2, 8)      // psa_1
   SAH_CASE(16, 16, 32, 32, false, 2, 8)     // psa_2

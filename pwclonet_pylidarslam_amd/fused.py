@@ -31,13 +31,23 @@ def fold_conv_bn(layer):
     return w.float(), b.float()
 
 
-def pack_layer(w, b, phys_map, nbo=None):
+def pack_layer(w, b, phys_map, nbo=None, kmajor_out=False):
     """Pack one folded layer.  ``phys_map``: for every physical input channel (length multiple of
-    16) the original input channel, or -1 for padding.  Output channels are padded to 16*nbo."""
+    16) the original input channel, or -1 for padding.  Output channels are padded to 16*nbo.
+    ``kmajor_out`` (cout <= 16): output channel c is produced on row 4*(c % 4) + c // 4, i.e. in lane group c % 4,
+    accumulator register c // 4 -- the "k-step major" order in which the NEXT layer needs only ceil(cout / 4) of its
+    four MFMA k-steps (its phys_map must be ``kstep_major_map(cout)``)."""
     cout, _ = w.shape
     nbi = len(phys_map) // 16
     assert len(phys_map) == 16 * nbi
     nbo = nbo or (cout + 15) // 16
+    if kmajor_out:
+        assert cout <= 16 and nbo == 1
+        rows = torch.tensor([4 * (c % 4) + c // 4 for c in range(cout)], dtype=torch.long, device=w.device)
+        w_perm = torch.zeros((16, w.shape[1]), dtype=w.dtype, device=w.device)
+        b_perm = torch.zeros((16,), dtype=b.dtype, device=b.device)
+        w_perm[rows], b_perm[rows] = w, b
+        w, b, cout = w_perm, b_perm, 16
     pm = torch.as_tensor(phys_map, dtype=torch.long, device=w.device)
     wphys = torch.zeros((16 * nbo, 16 * nbi), dtype=torch.float32, device=w.device)
     valid = pm >= 0
@@ -530,8 +540,21 @@ class FusedSAHoisted:
             first = pack_layer(w1[:, :3], _zeros_like_bias(w1), kstep_major_map(3), nbo1)
         else:
             self.pre_job = None
-            first = pack_layer(w1, b1, kstep_major_map(6), nbo1)
-        rest, widths = _pack_rest(layers[1:], w1.shape[0], self.wfmt)
+        # level 0 (6 -> 8 -> 8 -> 16): 8-channel layers on 16-wide MFMA blocks.  Producing them k-step major lets the
+        # consuming layer skip the two k-steps that would multiply padding: 2 + 2 + 2 MFMAs per block instead of 2 + 4 + 4.
+        w2 = layers[1].conv.weight.shape[0]
+        self.kmajor = int(self.c_feat == 0 and len(layers) == 3 and w1.shape[0] <= 8 and w2 <= 8
+                          and os.environ.get("PWCLO_SA_KMAJOR", "1") != "0")
+        if self.kmajor:
+            first = pack_layer(w1, b1, kstep_major_map(6), nbo1, kmajor_out=True)
+            wb2, wb3 = fold_conv_bn(layers[1]), fold_conv_bn(layers[2])
+            second = pack_layer(wb2[0], wb2[1], kstep_major_map(w1.shape[0]), 1, kmajor_out=True)
+            third = pack_layer(wb3[0], wb3[1], kstep_major_map(w2), (wb3[0].shape[0] + 15) // 16)
+            rest, widths = [second, third], [16, 16 * ((wb3[0].shape[0] + 15) // 16)]
+        else:
+            if not self.c_feat:
+                first = pack_layer(w1, b1, kstep_major_map(6), nbo1)
+            rest, widths = _pack_rest(layers[1:], w1.shape[0], self.wfmt)
         self.packed = torch.cat([first] + rest).contiguous()
         self.widths = [16 * nbo1] + widths
         self.c_out = layers[-1].conv.weight.shape[0]
@@ -548,7 +571,7 @@ class FusedSAHoisted:
         _lib.annotate(family="mlp", flops=2.0 * B * S * K * self.macs,
                       bytes=4.0 * B * (S * K * (1 + 3 + self.widths[0]) + 3 * S + S * self.c_out))
         _lib.call("sa_fused_h_kernel_wrapper", xyz.device, B, N, S, K, *self.widths, _p(xyz), _p(new_xyz),
-                  _p(pre), _p(idx), _p(self.packed), _p(out), self.wfmt, self.packed.numel())
+                  _p(pre), _p(idx), _p(self.packed), _p(out), self.wfmt, self.packed.numel(), self.kmajor)
         return out
 
 
