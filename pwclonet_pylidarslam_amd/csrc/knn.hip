@@ -619,7 +619,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_rows_kernel(int nblk, int 
                                                                   const float4 *__restrict__ boxes,
                                                                   const float *__restrict__ new_xyz,
                                                                   int *__restrict__ idx,
-                                                                  float *__restrict__ dist) {
+                                                                  float *__restrict__ dist, int settle_min) {
   TraceScope trace_scope_(TK_KNN_PRUNED, 15u);
   constexpr int Q = 64 / L, SUB = 64 / L;
   constexpr unsigned LMASK = L == 32 ? 0xFFFFFFFFu : 0xFFFFu;
@@ -749,13 +749,20 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_rows_kernel(int nblk, int 
         if (__ballot(cnt >= L || (bound == INF && cnt >= K)) != 0ull) fold_sort();
       }
     }
-    // end of the block: settle the survivors so that the bound is current, then move on
-    while (__ballot(cnt > 0) != 0ull) {
-      if (__ballot(cnt > INS_MAX) != 0ull) fold_sort();
-      else insert_all();
+    // end of the block: settle the survivors so that the bound is current (a row with fewer than settle_min pooled
+    // survivors keeps collecting: its bound stays a little loose, which is still exact), then move on
+    if (__ballot(cnt >= settle_min) != 0ull) {
+      while (__ballot(cnt > 0) != 0ull) {
+        if (__ballot(cnt > INS_MAX) != 0ull) fold_sort();
+        else insert_all();
+      }
     }
     const int nb = next_block();
     cur = active ? nb : -1;
+  }
+  while (__ballot(cnt > 0) != 0ull) {         // whatever is still pooled when the last row finishes
+    if (__ballot(cnt > INS_MAX) != 0ull) fold_sort();
+    else insert_all();
   }
   if (qvalid && p < K) {
     idx[((size_t)b * s + q) * K + p] = (int)bl;
@@ -764,6 +771,11 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_rows_kernel(int nblk, int 
 }
 
 }  // namespace pwclo
+
+static int knn_tune_early(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 
 static int knn_slabs(int n) {            // ~ sqrt(#blocks), power of two in [2,16]
   int nslab = 2;
@@ -815,10 +827,12 @@ static void knn_search_launch(int b, int n, int s, int nsample, const float *new
   if (use_rows < 0) { const char *e = getenv("PWCLO_KNN_ROWS"); use_rows = e ? atoi(e) : 1; }
   const int L = nsample <= 16 ? 16 : 32;
   const int need = ceil_div(nblk, L);
+  static const int settle16 = knn_tune_early("PWCLO_KNN_SETTLE16", 4), settle32 = knn_tune_early("PWCLO_KNN_SETTLE32", 16);
+  const int settle_min = L == 16 ? settle16 : settle32;
 #define KR_CASE(LL, RR)                                                                                        \
   if (L == LL && need <= RR) {                                                                                 \
     hipLaunchKernelGGL((knn_rows_kernel<LL, RR>), dim3(ceil_div(s, KNN_WAVES * (64 / LL)), b), dim3(KNN_WAVES * 64), \
-                       0, current_stream(), nblk, s, nsample, rows, boxes, new_xyz, idx, dist);                \
+                       0, current_stream(), nblk, s, nsample, rows, boxes, new_xyz, idx, dist, settle_min);    \
     check_launch("knn_point(rows)");                                                                           \
     return;                                                                                                    \
   }
