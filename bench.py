@@ -226,16 +226,17 @@ def cpu_baseline(net, npoints, timed=5, threads=0):
                          time.perf_counter() - t_all)}
 
 
-def bf16x3_variant(args, dev, x1, x2, pose_ref, streams):
-    """The same step with the opt-in PWCLO_BF16X3=1 stack layers (fp32 operands split into three bf16 terms on
-    the bf16 matrix pipe, fp32 accumulate), measured AFTER the headline region on the same
-    inputs and weights.  Reported beside the headline number, never as it."""
+def bf16x3_variant(args, dev, x1, x2, pose_ref, streams, dtype="bf16x3"):
+    """The same step with reduced-format stack layers, measured AFTER the headline region on the same inputs and
+    weights and reported beside the headline number, never as it: "bf16x3" = fp32 operands split into three bf16
+    terms on the bf16 matrix pipe, fp32 accumulate (fp32-accurate); "bf16" = the configs[4]
+    dtype (operands and hoisted / per-pixel rows rounded to bf16) at THIS workload."""
     from pwclonet_pylidarslam_amd.graphed import PipelinedForward
     try:
         torch.manual_seed(1234)
         net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(dev), scalar_last=False,
                             log_mode=args.log_mode)).to(dev).eval()
-        net.prepare_fused(dtype="bf16x3")
+        net.prepare_fused(dtype=dtype)
         pipe = PipelinedForward(net, depth=args.inflight, streams=streams)
         pipe.prepare(x1, x2)
         for _ in range(args.warmup):
@@ -250,8 +251,10 @@ def bf16x3_variant(args, dev, x1, x2, pose_ref, streams):
         pass
     return {"value": args.batch * args.steps / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt / args.steps,
             "max_abs_pose_diff_vs_headline": float((pose - pose_ref).abs().max()),
-            "note": "opt-in PWCLO_BF16X3=1; not the headline path.  The pose difference is dominated by one pair whose "
-                    "level-1 neighbour list differs between the two paths after the warp (DESIGN.md section 2)"}
+            "note": ("opt-in dtype=%s; not the headline path.  " % dtype) +
+                    ("The pose difference is dominated by pairs whose level-1 neighbour list differs between the two paths "
+                     "after the warp (DESIGN.md section 2)" if dtype == "bf16x3" else
+                     "bf16 operands: poses agree to ~1e-2 of their scale (tests/test_gpu_fused.py)")}
 
 
 def step_roofline(fam, ms_per_step):
@@ -590,7 +593,9 @@ def main():
         if not args.no_variants and world == 1 and pipe is not None and not args.unfused \
                 and args.pipeline == "whole" and (args.dtype or "f32") == "f32" \
                 and os.environ.get("PWCLO_BF16X3", "0") == "0":
-            out["variants"] = {"bf16x3": bf16x3_variant(args, dev, x1, x2, pose.clone(), pipe.streams)}
+            ref_pose = pose.clone()
+            out["variants"] = {"bf16x3": bf16x3_variant(args, dev, x1, x2, ref_pose, pipe.streams, "bf16x3"),
+                               "bf16": bf16x3_variant(args, dev, x1, x2, ref_pose, pipe.streams, "bf16")}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(net, args.npoints, args.cpu_forwards, args.cpu_threads)
         print(json.dumps(out), flush=True)

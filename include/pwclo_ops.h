@@ -235,7 +235,8 @@ void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int c2, int w1
  *     xyz1 (b,s,3), feat1 (b,s,c), xyz2 (b,n,3), feat2 (b,n,c), idx (b,s,k).
  * Packed-weight format (entry points that take `wfmt, packed_floats`): 0 = fp32 operand tiles
  *     (v_mfma_f32_16x16x4_f32), 1 = the opt-in three-term bf16 split tiles, 2 = bf16 tiles (dtype "bf16":
- *     v_mfma_f32_16x16x32_bf16 on operands rounded once, fp32 accumulate; csrc/mlp_core.hpp); the format is a
+ *     v_mfma_f32_16x16x32_bf16 on operands rounded once, fp32 accumulate; with it the hoisted rows pre / u / v / u2 / v2
+ *     and the per-pixel buffer pix are bf16 IN MEMORY too: 2 bytes per channel; csrc/mlp_core.hpp); the format is a
  *     property of the buffer, fixed when it was packed.  packed_floats = its length; a length that does not match
  *     the layout the selected kernel indexes is refused with PWCLO_EINVAL (never read out of bounds).
  * a2: mlp_conv_xyz_1(geometry10), mlp2_convs, softmax over k, sum_k w*pix -> out (b,s,64).
@@ -320,7 +321,8 @@ void batchnorm_train_backward_kernel_wrapper(int b, int c, int l, const float *x
  * cin_j) . W_j^T + bias_j, no activation; cin in {16,32,64}, cout in {16,32,64,128}; all seven
  * arrays are HOST arrays of length njobs (pointers inside are device pointers). */
 void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int *cin, const int *cout,
-                                const float *const *src, const float *const *w, float *const *out);
+                                const float *const *src, const float *const *w, float *const *out,
+                                const int *out_bf16 /* per job: 1 = write the rows as bf16 (dtype "bf16"); may be NULL */);
 
 /* sa_fused with pre (b,n,c1) = W1_feat . feat + b1 (NULL at level 0, where layer 1 is whole). */
 void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, int c2, int c3, const float *xyz,

@@ -66,8 +66,8 @@ SIGNATURES = {
     "cv_fused_b_kernel_wrapper": ([_i] * 4 + [_F] * 6, None),
     "masked_pool_kernel_wrapper": ([_i, _i, _F, _F, _F], None),
     "pose_head_fused_kernel_wrapper": ([_i, _i] + [_F] * 13 + [_i], None),
-    "linear_jobs_kernel_wrapper": ([_i] + [ctypes.POINTER(ctypes.c_int)] * 3 + [ctypes.POINTER(ctypes.c_void_p)] * 3,
-                                   None),
+    "linear_jobs_kernel_wrapper": ([_i] + [ctypes.POINTER(ctypes.c_int)] * 3 + [ctypes.POINTER(ctypes.c_void_p)] * 3
+                                   + [ctypes.POINTER(ctypes.c_int)], None),
     "sa_fused_h_kernel_wrapper": ([_i] * 7 + [_F] * 6 + [_i] * 3, None),
     "upconv_fused_h_kernel_wrapper": ([_i] * 4 + [_F] * 6 + [_i] * 2, None),
     "cv_fused_a1_h_kernel_wrapper": ([_i] * 4 + [_F] * 7 + [_i] * 3, None),

@@ -60,8 +60,9 @@ __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<
 struct LinJob {
   const float *src;   // (npts, 16*nbi) point-major
   const float *w;     // packed single layer (bias included, no activation)
-  float *out;         // (npts, 16*nbo)
+  float *out;         // (npts, 16*nbo); bf16 rows when out_bf16
   int npts, nbi, nbo;
+  int out_bf16;
 };
 struct LinArgs { LinJob job[6]; };
 constexpr int LIN_WAVES = 8;
@@ -84,13 +85,19 @@ __device__ __forceinline__ void linear_tiles(const LinJob &jb, const float *lds_
     }
     f32x4 o1[NBO][P];
     mlp_layer<NBI, NBO, P, false>(o1, in, lds_w, lane);
+    if (jb.out_bf16) {        // job-uniform
 #pragma unroll
-    for (int o = 0; o < NBO; ++o)
+      for (int o = 0; o < NBO; ++o)
 #pragma unroll
-      for (int p = 0; p < P; ++p)
-        if (pt[p] >= 0)
-          *reinterpret_cast<f32x4 *>(at32(jb.out, (unsigned)pt[p] * (unsigned)(64 * NBO) + 64u * o + 16u * (unsigned)g)) =
-              o1[o][p];
+        for (int p = 0; p < P; ++p)
+          if (pt[p] >= 0) st_group<true>(jb.out, (unsigned)pt[p], 16u * NBO, o, g, o1[o][p]);
+    } else {
+#pragma unroll
+      for (int o = 0; o < NBO; ++o)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          if (pt[p] >= 0) st_group<false>(jb.out, (unsigned)pt[p], 16u * NBO, o, g, o1[o][p]);
+    }
   }
 }
 
@@ -133,7 +140,8 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
     const unsigned bS = (unsigned)b * (unsigned)a.S, bN = (unsigned)b * (unsigned)a.N;   // scalar
     f32x4 in[1][P];
     int sq[P];
-    const float *prow[P];
+    unsigned psrc[P];
+    constexpr bool H16 = FMT == 2;                 // hoisted rows stored as bf16 (mlp_core.hpp)
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const PixelMap<KP> pm(pix0 + 16 * p + j);
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
       const float *q = at32(a.xyz, mul24(src, 12u));
       const float qx = q[0], qy = q[1], qz = q[2];
       in[0][p] = diff_block_h(qx - c[0], qy - c[1], qz - c[2], qx, qy, qz, XYZ_ONLY, g);
-      prow[p] = XYZ_ONLY ? nullptr : at32(a.pre, src * (unsigned)(C1 * 4) + 16u * (unsigned)g);
+      psrc[p] = src;
     }
     f32x4 h1[B1][P], h2[B2][P], h3[B3][P];
     if (XYZ_ONLY) {
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
 #pragma unroll
       for (int o = 0; o < B1; ++o)
 #pragma unroll
-        for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
+        for (int p = 0; p < P; ++p) h1[o][p] = ld_group<H16>(a.pre, psrc[p], (unsigned)C1, o, g);
       mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
     }
     if constexpr (KMAJ) {
@@ -215,7 +223,8 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
     const unsigned bS = (unsigned)b * (unsigned)a.S, bN = (unsigned)b * (unsigned)a.N;   // scalar
     f32x4 in[1][P];
     int sq[P];
-    const float *prow[P];
+    unsigned psrc[P];
+    constexpr bool H16 = FMT == 2;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const PixelMap<KP> pm(pix0 + 16 * p + j);
@@ -229,13 +238,13 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
       const unsigned src = bN + (unsigned)nbr;
       const float *q = at32(a.xyz1, mul24(src, 12u));
       in[0][p] = diff_block_h(q[0] - c[0], q[1] - c[1], q[2] - c[2], 0.f, 0.f, 0.f, false, g);
-      prow[p] = at32(a.pre, (src << 9) + 16u * (unsigned)g);          // 128 floats per row
+      psrc[p] = src;                                                  // 128 channels per row
     }
     f32x4 h1[B1][P], h2[B2][P];
 #pragma unroll
     for (int o = 0; o < B1; ++o)
 #pragma unroll
-      for (int p = 0; p < P; ++p) h1[o][p] = ld4(prow[p] + 16 * o);
+      for (int p = 0; p < P; ++p) h1[o][p] = ld_group<H16>(a.pre, psrc[p], 128u, o, g);
     mlp_layer_init<1, B1, P, true, 1>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // diff(3)
     mlp_layer_any<FMT, B1, B2, P, false>(h2, h1, lds_w + W1, lane);   // its ReLU is applied after the pool
     constexpr int GROUP = KP < 16 ? KP : 16;
@@ -341,7 +350,8 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
     const unsigned bPix = (unsigned)b * (unsigned)pix_per_cloud;
     f32x4 in[1][P];
     int pixv[P];
-    const float *urow[P], *vrow[P];
+    unsigned urow[P], vrow[P];
+    constexpr bool H16 = FMT == 2;                 // u / v rows in, per-pixel features out: bf16
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int pix = pix0 + 16 * p + j;
@@ -354,14 +364,15 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
       const int nbr = *at32(a.idx, (mul24(row, (unsigned)a.K) + (unsigned)k) * 4u);
       const unsigned src = bN + (unsigned)nbr;
       in[0][p] = geometry_block_h(at32(a.xyz1, mul24(row, 12u)), at32(a.xyz2, mul24(src, 12u)), g);
-      urow[p] = at32(a.u, (row << 9) + 16u * (unsigned)g);
-      vrow[p] = at32(a.v, (src << 9) + 16u * (unsigned)g);
+      urow[p] = row;
+      vrow[p] = src;
     }
     f32x4 h1[B1][P], h2[B2][P], h3[B3][P];
 #pragma unroll
     for (int o = 0; o < B1; ++o)
 #pragma unroll
-      for (int p = 0; p < P; ++p) h1[o][p] = ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o);
+      for (int p = 0; p < P; ++p)
+        h1[o][p] = ld_group<H16>(a.u, urow[p], 128u, o, g) + ld_group<H16>(a.v, vrow[p], 128u, o, g);
     mlp_layer_init<1, B1, P, true, 3>(h1, in, lds_w, lane, [&](int o, int p) { return h1[o][p]; });   // geometry(10)
     mlp_layer_any<FMT, B1, B2, P, true>(h2, h1, lds_w + W1, lane);
     mlp_layer_any<FMT, B2, B3, P, true>(h3, h2, lds_w + W1 + W2, lane);
@@ -369,9 +380,7 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
     for (int o = 0; o < B3; ++o)
 #pragma unroll
       for (int p = 0; p < P; ++p)
-        if (pixv[p] >= 0)
-          *reinterpret_cast<f32x4 *>(at32(a.out, ((bPix + (unsigned)pixv[p]) << 8) + 64u * o + 16u * (unsigned)g)) =
-              h3[o][p];
+        if (pixv[p] >= 0) st_group<H16>(a.out, bPix + (unsigned)pixv[p], 64u, o, g, h3[o][p]);
   }
 }
 
@@ -390,7 +399,8 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
     f32x4 geo[1][P], val[4][P];
     int sq[P];
     bool padded[P];
-    const float *urow[P], *vrow[P];
+    unsigned urow[P], vrow[P];
+    constexpr bool H16 = FMT == 2;                 // u2 / v2 rows: bf16 (the gathered values `first` stay fp32)
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const PixelMap<KP> pm(pix0 + 16 * p + j);
@@ -403,8 +413,8 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
       const int nbr = *at32(a.idx, (mul24(row, (unsigned)a.K) + (unsigned)k) * 4u);
       const unsigned src = bN + (unsigned)nbr;
       geo[0][p] = geometry_block_h(at32(a.xyz1, mul24(row, 12u)), at32(a.xyz2, mul24(src, 12u)), g);
-      urow[p] = at32(a.u, (row << 9) + 16u * (unsigned)g);
-      vrow[p] = at32(a.v, (src << 9) + 16u * (unsigned)g);
+      urow[p] = row;
+      vrow[p] = src;
       const float *fr = at32(a.val, (src << 8) + 16u * (unsigned)g);
 #pragma unroll
       for (int m = 0; m < 4; ++m) val[m][p] = ld4(fr + 16 * m);
@@ -413,7 +423,8 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
 #pragma unroll
     for (int o = 0; o < 8; ++o)
 #pragma unroll
-      for (int p = 0; p < P; ++p) h1[o][p] = ld4(urow[p] + 16 * o) + ld4(vrow[p] + 16 * o);
+      for (int p = 0; p < P; ++p)
+        h1[o][p] = ld_group<H16>(a.u, urow[p], 128u, o, g) + ld_group<H16>(a.v, vrow[p], 128u, o, g);
     mlp_layer<1, 4, P, true, 3>(enc, geo, lds_w, lane);
     mlp_layer_any_init<FMT, 4, 8, P, true>(h1, enc, lds_w + WX, lane, [&](int o, int p) { return h1[o][p]; });
     mlp_layer_any<FMT, 8, 4, P, true>(h2, h1, lds_w + WX + W1, lane);
@@ -465,7 +476,7 @@ using namespace pwclo;
 
 extern "C" void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int *cin, const int *cout,
                                            const float *const *src, const float *const *w,
-                                           float *const *out) {
+                                           float *const *out, const int *out_bf16) {
   if (njobs <= 0) return;
   PWCLO_REQUIRE(njobs <= 6, "linear_jobs: at most 6 jobs per launch (got %d)", njobs);
   LinArgs a;
@@ -475,7 +486,7 @@ extern "C" void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int
                     (cout[i] == 16 || cout[i] == 32 || cout[i] == 64 || cout[i] == 128);
     PWCLO_REQUIRE(ok, "linear_jobs: job %d has unsupported channels %d -> %d", i, cin[i], cout[i]);
     PWCLO_REQUIRE(rows_fit_32bit(npts[i]), "linear_jobs: job %d has too many rows for 32-bit offsets (%d)", i, npts[i]);
-    a.job[i] = LinJob{src[i], w[i], out[i], npts[i], cin[i] / 16, cout[i] / 16};
+    a.job[i] = LinJob{src[i], w[i], out[i], npts[i], cin[i] / 16, cout[i] / 16, out_bf16 ? out_bf16[i] : 0};
     max_tiles = max(max_tiles, ceil_div(npts[i], 32));
     max_lds = max(max_lds, 4 * layer_floats(cin[i] / 16, cout[i] / 16));
   }

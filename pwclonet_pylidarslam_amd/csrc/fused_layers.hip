@@ -42,6 +42,12 @@ __device__ __forceinline__ void load_row_blocks(f32x4 *dst, int stride_p, const 
 #pragma unroll
   for (int m = 0; m < NB; ++m) dst[m * stride_p] = *reinterpret_cast<const f32x4 *>(row + 16 * m + 4 * g);
 }
+// the cost volume's per-pixel features (64 channels): bf16 rows when the stack format is bf16 (mlp_core.hpp)
+template <bool H16>
+__device__ __forceinline__ void load_pix_blocks(f32x4 *dst, int stride_p, const float *pix, unsigned slot, int g) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) dst[m * stride_p] = ld_group<H16>(pix, slot, 64u, m, g);
+}
 
 // Softmax over the K neighbours of each query (dim=3 of the reference's (B,C,S,K) tensor) and
 // weighted sum of `val`; logits are post-ReLU (>= 0), padded neighbour slots carry weight 0.
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
       geo[0][p] = geometry_block(at32(a.xyz1, mul24(row, 12u)), at32(a.xyz2, mul24(src, 12u)), g);
       // padded slots (masked below) re-read slot 0's row: a1 does not write them, no extra traffic
       const int pixc = valid ? pix - (padded[p] ? pm.k : 0) : pix_per_cloud - KP;
-      load_row_blocks<4>(&cat[4][p], P, at32(a.pix, ((unsigned)b * (unsigned)pix_per_cloud + (unsigned)pixc) << 8), g);
+      load_pix_blocks<FMT == 2>(&cat[4][p], P, a.pix, (unsigned)b * (unsigned)pix_per_cloud + (unsigned)pixc, g);
     }
     f32x4 enc[4][P];
     mlp_layer<1, 4, P, true>(enc, geo, lds_w, lane);
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
       const int nbr = *at32(a.idx, slot * 4u);
       const unsigned src = (unsigned)b * (unsigned)a.N + (unsigned)nbr;
       geo[0][p] = geometry_block(at32(a.xyz1, mul24(row, 12u)), at32(a.xyz2, mul24(src, 12u)), g);
-      load_row_blocks<4>(&cat[4][p], P, at32(a.pix, slot << 8), g);
+      load_pix_blocks<FMT == 2>(&cat[4][p], P, a.pix, slot, g);
     }
     f32x4 h2[4][P];
     if constexpr (FMT != 0) {

@@ -408,6 +408,37 @@ __device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) { return __umu
 // must be addressable with 32 bits (and rows < 2^24 for mul24): 8.3 M rows, e.g. batch 1024 of 8192-point clouds.
 static inline bool rows_fit_32bit(long long rows) { return rows >= 0 && rows < (1ll << 23); }
 
+// ---- bf16 STORAGE of intermediate feature rows (dtype = "bf16") ---------------------------------------------------
+// With FMT == 2 the hoisted partial products (linear_jobs outputs gathered K times per pixel: most of the gathered
+// bytes of a forward) and the cost volume's per-pixel feature buffer live in HBM as bf16: a 4-channel group is 8 bytes
+// instead of 16.  Values are rounded once (round to nearest even) when written and widened exactly when read; point
+// features between modules, coordinates, distances and indices stay fp32.
+__device__ __forceinline__ f32x4 ld4_bf16(const void *p) {          // 4 consecutive bf16 -> fp32 (exact)
+  const uint2 v = *reinterpret_cast<const uint2 *>(p);
+  f32x4 r;
+  r.x = __uint_as_float(v.x << 16); r.y = __uint_as_float(v.x & 0xFFFF0000u);
+  r.z = __uint_as_float(v.y << 16); r.w = __uint_as_float(v.y & 0xFFFF0000u);
+  return r;
+}
+__device__ __forceinline__ void st4_bf16(void *p, const f32x4 v) {  // fp32 -> 4 bf16, round to nearest even
+  const bf16x2 a = {(__bf16)v.x, (__bf16)v.y}, b = {(__bf16)v.z, (__bf16)v.w};
+  uint2 o;
+  o.x = *reinterpret_cast<const unsigned *>(&a);
+  o.y = *reinterpret_cast<const unsigned *>(&b);
+  *reinterpret_cast<uint2 *>(p) = o;
+}
+// Row of C channels, 4-channel group (block o, lane group g): fp32 rows are 4*C bytes, bf16 rows 2*C.
+template <bool H16>
+__device__ __forceinline__ f32x4 ld_group(const float *base, unsigned row, unsigned c, int o, int g) {
+  if constexpr (H16) return ld4_bf16(at32(base, row * (2u * c) + 32u * (unsigned)o + 8u * (unsigned)g));
+  else return *reinterpret_cast<const f32x4 *>(at32(base, row * (4u * c) + 64u * (unsigned)o + 16u * (unsigned)g));
+}
+template <bool H16>
+__device__ __forceinline__ void st_group(float *base, unsigned row, unsigned c, int o, int g, const f32x4 v) {
+  if constexpr (H16) st4_bf16(at32(base, row * (2u * c) + 32u * (unsigned)o + 8u * (unsigned)g), v);
+  else *reinterpret_cast<f32x4 *>(at32(base, row * (4u * c) + 64u * (unsigned)o + 16u * (unsigned)g)) = v;
+}
+
 // pixel index -> (query s, neighbour slot k).
 template <int KP>
 struct PixelMap {

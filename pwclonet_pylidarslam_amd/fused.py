@@ -365,6 +365,8 @@ class FusedCostVolume:
         self.nsample, self.nsample_q = module.nsample, module.nsample_q
         self.kp = cv_pix_slots(module.nsample_q)               # per-pixel buffer layout, fixed at pack time
         self.wfmt_a2 = default_wfmt() if self.kp in (6, 32) else WFMT_F32
+        if self.wfmt_a2 == WFMT_BF16:
+            self.wfmt_a2 = WFMT_F32        # the un-hoisted cv_a1 writes fp32 per-pixel features; bf16 rows belong to the hoisted set
         geo = list(range(10)) + [-1] * 6
         # mlp_convs input (costvolume.py:105-110): [geometry10, feat1 (C), feat2 gathered (C)]
         self.w_a1, w = pack_stack(module.mlp_convs, geo + [10 + c for c in range(2 * c1)])
@@ -449,12 +451,14 @@ class FusedPoseHead:
 # ---- hoisted first layers (csrc/fused_hoisted.hip) ------------------------------------------------------
 
 class LinearJob:
-    """out = src . W^T + bias over points (no activation): one hoisted partial product."""
+    """out = src . W^T + bias over points (no activation): one hoisted partial product.  ``out_bf16``: the rows are
+    written (and later gathered) as bf16 -- set by consumers packed with dtype "bf16" (csrc/mlp_core.hpp)."""
 
-    def __init__(self, w, b):
+    def __init__(self, w, b, out_bf16=False):
         self.cout, self.cin = w.shape
         assert self.cin in (16, 32, 64) and self.cout in (16, 32, 64, 128)
         self.packed = pack_layer(w, b, list(range(self.cin)))
+        self.out_bf16 = bool(out_bf16)
 
 
 def run_linear_jobs(jobs):
@@ -466,7 +470,8 @@ def run_linear_jobs(jobs):
         chunk = jobs[start:start + 6]
         n = len(chunk)
         srcs = [s_ for _, s_ in chunk]
-        res = [torch.empty(s_.shape[:-1] + (j.cout,), dtype=torch.float32, device=s_.device) for j, s_ in chunk]
+        res = [torch.empty(s_.shape[:-1] + (j.cout,), dtype=torch.bfloat16 if j.out_bf16 else torch.float32,
+                           device=s_.device) for j, s_ in chunk]
         npts = [s_.shape[0] * s_.shape[1] for s_ in srcs]
         ia = lambda v: (ctypes.c_int * n)(*v)
         pa = lambda v: (ctypes.c_void_p * n)(*v)
@@ -474,7 +479,8 @@ def run_linear_jobs(jobs):
                       bytes=4.0 * sum(p_ * (j.cin + j.cout) for p_, (j, _) in zip(npts, chunk)))
         _lib.call("linear_jobs_kernel_wrapper", srcs[0].device, n, ia(npts), ia([j.cin for j, _ in chunk]),
                   ia([j.cout for j, _ in chunk]), pa([_p(s_) for s_ in srcs]),
-                  pa([_p(j.packed) for j, _ in chunk]), pa([_p(r) for r in res]))
+                  pa([_p(j.packed) for j, _ in chunk]), pa([_p(r) for r in res]),
+                  ia([int(j.out_bf16) for j, _ in chunk]))
         outs.extend(res)
     return outs
 
@@ -536,7 +542,8 @@ class FusedSAHoisted:
         self.wfmt = default_wfmt()
         if self.c_feat:
             # original order [xyz_diff(3), feat(C)] (pointnet2_modules.py:222)
-            self.pre_job = LinearJob(_pad_rows(w1[:, 3:], 16 * nbo1), _pad_rows(b1, 16 * nbo1))
+            self.pre_job = LinearJob(_pad_rows(w1[:, 3:], 16 * nbo1), _pad_rows(b1, 16 * nbo1),
+                                     out_bf16=self.wfmt == WFMT_BF16)
             first = pack_layer(w1[:, :3], _zeros_like_bias(w1), kstep_major_map(3), nbo1)
         else:
             self.pre_job = None
@@ -591,8 +598,8 @@ class FusedUpconvHoisted:
         layers = list(module.mlp)
         w1, b1 = fold_conv_bn(layers[0])
         assert w1.shape == (128, 67), "set-upconv kernel is built for 64-channel coarse features"
-        self.pre_job = LinearJob(w1[:, :64], b1)                     # original order [feat(64), diff(3)], :490
         self.wfmt = default_wfmt()
+        self.pre_job = LinearJob(w1[:, :64], b1, out_bf16=self.wfmt == WFMT_BF16)   # original order [feat(64), diff(3)], :490
         first = pack_layer(w1[:, 64:67], _zeros_like_bias(w1), kstep_major_map(3), 8)
         rest, widths = _pack_rest(layers[1:], 128, self.wfmt)
         assert widths == [64]
@@ -627,12 +634,15 @@ class FusedCostVolumeHoisted:
         self.nsample, self.nsample_q = module.nsample, module.nsample_q
         self.kp = cv_pix_slots(module.nsample_q)               # per-pixel buffer layout, fixed at pack time
         self.wfmt = default_wfmt()
-        self.wfmt_a2 = self.wfmt if self.kp in (6, 32) else WFMT_F32
+        if self.kp not in (6, 32) and self.wfmt != WFMT_F32:
+            self.wfmt = WFMT_F32                               # cv_a2 has reduced formats for 6 / 32 pixel slots only
+        self.wfmt_a2 = self.wfmt
+        h16 = self.wfmt == WFMT_BF16                           # hoisted rows and the per-pixel buffer stored as bf16
         geo = list(range(10)) + [-1] * 6
         la = list(module.mlp_convs)
         w1, b1 = fold_conv_bn(la[0])                                   # [geo(10) | feat1 (C) | feat2 (C)]
-        self.job_u = LinearJob(w1[:, 10:10 + c], b1)
-        self.job_v = LinearJob(w1[:, 10 + c:10 + 2 * c], _zeros_like_bias(w1))
+        self.job_u = LinearJob(w1[:, 10:10 + c], b1, out_bf16=h16)
+        self.job_v = LinearJob(w1[:, 10 + c:10 + 2 * c], _zeros_like_bias(w1), out_bf16=h16)
         first = pack_layer(w1[:, :10], _zeros_like_bias(w1), kstep_major_map(10), 8)
         rest, widths = _pack_rest(la[1:], 128, self.wfmt)
         assert widths == [64, 64]
@@ -644,8 +654,8 @@ class FusedCostVolumeHoisted:
         wx2, _ = pack_stack(module.mlp_conv_xyz_2, kstep_major_map(10))
         lb = list(module.mlp3_convs)
         w3, b3 = fold_conv_bn(lb[0])                                   # [enc2 (64) | feat1 (C) | first (64)]
-        self.job_u2 = LinearJob(w3[:, 64:64 + c], b3)
-        self.job_v2 = LinearJob(w3[:, 64 + c:], _zeros_like_bias(w3))
+        self.job_u2 = LinearJob(w3[:, 64:64 + c], b3, out_bf16=h16)
+        self.job_v2 = LinearJob(w3[:, 64 + c:], _zeros_like_bias(w3), out_bf16=h16)
         first_b = pack_layer_any(w3[:, :64], _zeros_like_bias(w3), list(range(64)), 8, self.wfmt)
         rest_b, wdb = _pack_rest(lb[1:], 128, self.wfmt)
         assert wdb == [64]
@@ -666,7 +676,7 @@ class FusedCostVolumeHoisted:
         if idx_q is None:
             idx_q = knn(kq, xyz2, xyz1)
         kp = self.kp
-        pix = torch.empty((B, S * kp, 64), dtype=torch.float32, device=dev)
+        pix = torch.empty((B, S * kp, 64), dtype=torch.bfloat16 if self.wfmt == WFMT_BF16 else torch.float32, device=dev)
         _lib.annotate(family="mlp", kernel=_kname("cv_a1_h_kernel<%d, 1, 16>" % kp, self.wfmt),
                       flops=2.0 * B * S * kq * (self.macs_a1 - 2 * c * 128),
                       bytes=4.0 * B * (S * kq * (1 + 3 + 128 + 64) + S * (3 + 128)))
