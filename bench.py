@@ -513,7 +513,7 @@ def main():
     _lib.load()
     torch.manual_seed(1234)
     net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(dev), scalar_last=False,
-                        log_mode=args.log_mode)).to(dev).eval()
+                        log_mode=args.log_mode, fused="off" if args.unfused else "auto")).to(dev).eval()
     if not args.unfused:
         net.prepare_fused(dtype=args.dtype)
     x1, x2 = make_batch(args.batch, args.npoints, 1000 + rank, dev)

@@ -178,7 +178,7 @@ def test_fps_with_xyz_and_point_major_warp(cuda):
 
 def _net(dev):
     net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(dev), scalar_last=False,
-                        log_mode="none"))
+                        log_mode="none", fused="off"))      # "off": these tests pack explicitly and compare with the module graph
     params.fill_state_dict(net.state_dict())
     return net.to(dev).eval()
 
@@ -276,7 +276,8 @@ def test_prediction_module_adapter_matches_forward(cuda):
     f1 = torch.from_numpy(pc1[:, :, :3]).contiguous().to(cuda)        # (B, 2304, 3)
     f2 = torch.from_numpy(pc2[:, :, :3]).contiguous().to(cuda)
     mod = PWCLONetPredictionModule(dict(device=str(cuda), num_input_channels=3, sequence_len=2, num_points=2048,
-                                        nb_levels=4, scalar_last=False, posenet_config=dict(log_mode="device")))
+                                        nb_levels=4, scalar_last=False,
+                                        posenet_config=dict(log_mode="device", fused="off")))   # module route first
     params.fill_state_dict(mod.pwclonet.state_dict())
     mod = mod.to(cuda).eval()
     x1 = f1[:, :2048].permute(0, 2, 1).contiguous()
@@ -529,3 +530,29 @@ def test_fps_slab_pruned_sampler_matches_oracle_and_classic_kernel(cuda):
     # without a chain record
     idx2, _, _ = fused.fps_slab_with_xyz(x[:2].contiguous().to(cuda), 700)
     assert torch.equal(idx2.cpu(), ref[:2, :700])
+
+
+def test_eval_no_grad_forward_packs_itself(cuda):
+    """Drop-in behaviour: a user of the reference who only swaps the import calls
+    ``net.eval(); with torch.no_grad(): net(...)``.  With the default config that call packs the weights on first use
+    and runs the fused kernels (same pose within the contract); a forward with autograd enabled keeps the module graph
+    (the fused path has no backward), ``fused="off"`` keeps it always, ``train()`` drops the packed weights."""
+    pc1, pc2 = synthetic.uniform_pair(5, 1024, 2)
+    x1 = torch.from_numpy(pc1[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    x2 = torch.from_numpy(pc2[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(cuda), scalar_last=False, log_mode="none"))
+    params.fill_state_dict(net.state_dict())
+    net = net.to(cuda).eval()
+    assert net._fused is None
+    module_pose, _ = net(x1, None, x2, None)            # autograd enabled: module graph, nothing packed
+    assert net._fused is None and module_pose.requires_grad
+    with torch.no_grad():
+        fused_pose, _ = net(x1, None, x2, None)
+    assert net._fused is not None
+    pose_close(fused_pose, module_pose.detach(), "auto-packed no-grad forward vs module graph")
+    net.train()
+    assert net._fused is None
+    off = _net(cuda)
+    with torch.no_grad():
+        off(x1, None, x2, None)
+    assert off._fused is None
