@@ -238,7 +238,8 @@ def test_fused_forward_is_bitwise_deterministic_and_graph_safe(cuda):
     from pwclonet_pylidarslam_amd.graphed import StagedPipeline
     staged = StagedPipeline(net, slots=3)
     x1b = x1.flip(0).contiguous()                  # a second, different batch: slots must not mix them up
-    ref_b, _ = net(x1b, None, x2, None)
+    with torch.no_grad():                          # the fused route is the no-grad route
+        ref_b, _ = net(x1b, None, x2, None)
     got = []
     for i in range(8):
         o, slot = staged(x1b if i % 2 else x1, x2)
