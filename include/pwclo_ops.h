@@ -311,6 +311,23 @@ void batchnorm_train_backward_kernel_wrapper(int b, int c, int l, const float *x
                                              const float *save_invstd, float *dx, float *dgamma, float *dbeta,
                                              void *workspace, int relu);
 
+/* Pointwise convolution of the module path's shared MLPs, forward and both gradients, on channel-major rows
+ * (P2/pytorch_utils.py:114-167: Conv2d(kernel_size=(1,1), bias=False) inside SharedMLP, pytorch_utils.py:12-37;
+ * the reference runs torch.nn.Conv2d = cuDNN there).  x (b, cin, p), y (b, cout, p), p = product of the trailing
+ * dimensions, p % 4 == 0, all pointers 16-byte aligned, cin and cout <= 512 with the packed weights within 150 KiB
+ * of LDS (ceil(cin/16) * min(ceil(cout/16), 8) KiB).  fp32 FMAs on the matrix cores: equal to any fp32 convolution
+ * up to summation order.
+ *   transposed = 0: y[b][o][q] = sum_i w[o * cin + i] x[b][i][q]            (w (cout, cin) row-major: forward)
+ *   transposed = 1: y[b][o][q] = sum_i w[i * cout + o] x[b][i][q]           (w (cin, cout) row-major: the input
+ *                   gradient of the layer whose weight is w, called with x = dY, cin = the layer's cout). */
+void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w, int transposed,
+                                    float *y);
+/* dw (cout, cin) = sum over b, q of dy[b][o][q] x[b][i][q], summed in a fixed order (deterministic).  workspace:
+ * conv1x1_wgrad_workspace_bytes(b, cin, cout, p) bytes of device memory, 16-byte aligned. */
+long long conv1x1_wgrad_workspace_bytes(int b, int cin, int cout, int p);
+void conv1x1_wgrad_kernel_wrapper(int b, int cin, int cout, int p, const float *dy, const float *x, float *dw,
+                                  void *workspace);
+
 /* ---- 4. hoisted variants of section 3 ----------------------------------------------------------
  * The first layer of every grouped MLP is linear in [geometry | feat_centre[s] | feat_nbr[n]]; the
  * feature parts depend on one point only, so W_feat . feat[point] (+ bias) is computed once per

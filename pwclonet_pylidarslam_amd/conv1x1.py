@@ -1,0 +1,93 @@
+"""Pointwise convolution of the module path's shared MLPs on the HIP kernels of ``csrc/conv1x1.hip`` (SURVEY.md
+section 8 row f3): forward, input gradient and weight gradient on the fp32 matrix cores, on the ``(B, C, S, K)``
+channel-major activations as they are (no NHWC transposes).
+
+``conv1x1(x, weight)`` has the semantics of ``torch.nn.functional.conv{1,2,3}d(x, weight)`` for a kernel of size 1,
+stride 1, no padding, no bias (P2/pytorch_utils.py:114-167 builds exactly these inside SharedMLP); anything else
+stays on torch (``supported`` says which).  The three products are fp32 FMAs, so results equal torch's up to
+summation order; the weight gradient is summed in a fixed order (deterministic).
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+
+def _shape(x, weight):
+    B, Cin = x.shape[0], x.shape[1]
+    return B, Cin, weight.shape[0], x.numel() // max(B * Cin, 1)
+
+
+def _aligned(t):
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
+def _fits(cin, cout):
+    nbi, nbo = -(-cin // 16), -(-cout // 16)
+    gy = -(-nbo // 8)
+    return nbi * (-(-nbo // gy)) <= 150                      # KiB of LDS for the packed weights
+
+
+def supported(x, conv):
+    """True when ``conv(x)`` is a bias-free pointwise convolution these kernels cover (forward and both gradients)."""
+    if not (isinstance(conv, (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Conv3d)) and x.is_cuda
+            and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and conv.bias is None
+            and conv.groups == 1 and conv.padding_mode == "zeros"):
+        return False
+    if any(k != 1 for k in conv.kernel_size) or any(s != 1 for s in conv.stride) or any(d != 1 for d in conv.dilation):
+        return False
+    if isinstance(conv.padding, str) or any(p != 0 for p in conv.padding):
+        return False
+    if x.dim() != conv.weight.dim() or x.shape[1] != conv.in_channels or x.numel() == 0:
+        return False
+    cin, cout = conv.in_channels, conv.out_channels
+    P = x.numel() // (x.shape[0] * cin)
+    if P % 4 != 0 or cin > 512 or cout > 512 or x.shape[0] * (-(-P // 64)) >= 2 ** 31:
+        return False
+    tiles = (-(-cin // 16)) * (-(-cout // 16))
+    ph = 1 if tiles >= 5 else 2 if tiles >= 3 else 4 if tiles == 2 else 8
+    return (_fits(cin, cout) and _fits(cout, cin) and 2 * (cin + cout) * 36 * 4 <= 150 * 1024
+            and -(-tiles // (8 // ph)) <= 12)
+
+
+def _forward(x, w2d, transposed, cin, cout):
+    B = x.shape[0]
+    P = x.numel() // (B * cin)
+    y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    _lib.call("conv1x1_forward_kernel_wrapper", x.device, B, cin, cout, P, x.data_ptr(), w2d.data_ptr(),
+              int(transposed), y.data_ptr())
+    return y
+
+
+class _Conv1x1(Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = _aligned(x)
+        w = _aligned(weight.detach())
+        B, cin, cout, P = _shape(x, w)
+        ctx.save_for_backward(x, weight)
+        return _forward(x, w, False, cin, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _aligned(dy)
+        w = _aligned(weight.detach())
+        B, cin, cout, P = _shape(x, w)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _forward(dy, w, True, cout, cin)                     # dX = W^T dY: same kernel, transposed view
+        if ctx.needs_input_grad[1]:
+            nbytes = _lib.load().conv1x1_wgrad_workspace_bytes(B, cin, cout, P)
+            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+            dw = torch.empty_like(w)
+            _lib.call("conv1x1_wgrad_kernel_wrapper", x.device, B, cin, cout, P, dy.data_ptr(), x.data_ptr(),
+                      dw.data_ptr(), ws.data_ptr())
+            dw = dw.view_as(weight)
+        return dx, dw
+
+
+def conv1x1(x, weight):
+    """``F.conv{1,2,3}d(x, weight)`` for a size-1 kernel: x (B, Cin, *), weight (Cout, Cin, 1[, 1[, 1]])."""
+    return _Conv1x1.apply(x, weight)

@@ -10,8 +10,19 @@ import torch.nn as nn
 
 from . import _ext
 from .. import batchnorm as _hip_bn
+from .. import conv1x1 as _hip_conv
 
 _USE_HIP_BN = os.environ.get("PWCLO_HIP_BN", "1") != "0"
+# pointwise convolutions on csrc/conv1x1.hip: "grad" (default) = whenever autograd records the layer (training and
+# gradient checks), "all" = every GPU call, "0" = torch's convolution everywhere
+_USE_HIP_CONV = os.environ.get("PWCLO_HIP_CONV", "grad")
+
+
+def _conv(conv, x):
+    if _USE_HIP_CONV != "0" and x.is_cuda and _hip_conv.supported(x, conv) and (
+            _USE_HIP_CONV == "all" or (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))):
+        return _hip_conv.conv1x1(x, conv.weight)
+    return conv(x)
 
 
 def _nn_distance(pc1, pc2):
@@ -95,11 +106,13 @@ class _ConvBlock(nn.Sequential):
         mods = list(self)
         if (_USE_HIP_BN and len(mods) == 3 and isinstance(mods[1], _BN) and type(mods[2]) is nn.ReLU
                 and isinstance(mods[0], (nn.Conv1d, nn.Conv2d, nn.Conv3d)) and mods[1][0].training):
-            y = mods[0](x)
+            y = _conv(mods[0], x)
             if _hip_bn.supported(y, mods[1][0]):
                 return _hip_bn.batch_norm_train(y, mods[1][0], relu=True)
             return mods[2](mods[1](y))
-        return super().forward(x)
+        for m in mods:
+            x = _conv(m, x) if isinstance(m, (nn.Conv1d, nn.Conv2d, nn.Conv3d)) else m(x)
+        return x
 
 
 class Conv1d(_ConvBlock):

@@ -1,0 +1,146 @@
+"""Pointwise convolution kernels of the module path (csrc/conv1x1.hip) against a float64
+restatement of torch.nn.functional.conv2d (what P2/pytorch_utils.py:114-167 runs) -- forward, input gradient and
+weight gradient for every (cin, cout) the network's SharedMLPs hold, ragged pixel counts, determinism, and the drop-in
+through the Conv2d building block."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# every bias-free Conv2d shape of PWCLO-Net (tests/test_host_cpu.py pins this list against the model)
+NET_SHAPES = [(6, 8), (8, 8), (8, 16), (10, 64), (16, 16), (16, 32), (19, 16), (32, 32), (32, 64), (35, 32), (42, 128),
+              (64, 64), (64, 128), (67, 64), (67, 128), (74, 128), (80, 64), (96, 64), (128, 64), (128, 128),
+              (138, 128), (144, 128), (160, 128), (192, 128)]
+
+
+def _ref(x, w, dy):
+    x64, w64, dy64 = x.double(), w.double(), dy.double()
+    y = torch.einsum("oi,bip->bop", w64, x64)
+    dx = torch.einsum("oi,bop->bip", w64, dy64)
+    dw = torch.einsum("bop,bip->oi", dy64, x64)
+    return y, dx, dw
+
+
+def _run(x, w, dy):
+    from pwclonet_pylidarslam_amd import conv1x1
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = conv1x1.conv1x1(xr, wr.view(w.shape[0], w.shape[1], 1))
+    y.backward(dy)
+    return y.detach(), xr.grad, wr.grad
+
+
+def _check(got, ref, what, rel=1e-5):
+    # fp32 FMAs in another order than a float64 sum: bound relative to the tensor's scale
+    scale = ref.abs().max().item()
+    err = (got.double() - ref).abs().max().item()
+    assert err <= rel * scale + 1e-30, (what, err, scale)
+    return err / max(scale, 1e-30)
+
+
+@pytest.mark.parametrize("cin,cout", NET_SHAPES)
+def test_conv1x1_forward_and_gradients_match_float64(cuda, cin, cout):
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    B, P = 3, 2052                                           # 2052 = 32 tiles of 64 + a ragged tail of 4 pixels
+    x = torch.randn(B, cin, P, generator=g).to(cuda)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(cuda)
+    dy = torch.randn(B, cout, P, generator=g).to(cuda)
+    y, dx, dw = _run(x, w, dy)
+    ry, rdx, rdw = _ref(x, w, dy)
+    _check(y, ry, "y")
+    _check(dx, rdx, "dx")
+    _check(dw, rdw, "dw")
+
+
+@pytest.mark.parametrize("B,P", [(1, 4), (2, 8), (1, 60), (5, 64), (2, 68), (1, 16384), (7, 1028)])
+def test_conv1x1_ragged_pixel_counts(cuda, B, P):
+    g = torch.Generator().manual_seed(B * 100000 + P)
+    for cin, cout in ((6, 8), (67, 128), (192, 128)):
+        x = torch.randn(B, cin, P, generator=g).to(cuda)
+        w = torch.randn(cout, cin, generator=g).to(cuda)
+        dy = torch.randn(B, cout, P, generator=g).to(cuda)
+        y, dx, dw = _run(x, w, dy)
+        ry, rdx, rdw = _ref(x, w, dy)
+        _check(y, ry, "y")
+        _check(dx, rdx, "dx")
+        _check(dw, rdw, "dw")
+
+
+def test_conv1x1_large_layer_is_deterministic_and_close_to_torch(cuda):
+    """A full-size layer of the level-1 set-upconv (B=8 here): 128 -> 128 over 131072 pixels.  Two runs are
+    bit-identical (fixed summation order, no atomics); against torch's own convolution the three results agree to the
+    fp32 summation-order bound; timing of both printed for information."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    B, cin, cout, S, K = 8, 128, 128, 2048, 8
+    x = torch.randn(B, cin, S, K, generator=g).to(cuda)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(cuda)
+    dy = torch.randn(B, cout, S, K, generator=g).to(cuda)
+    from pwclonet_pylidarslam_amd import conv1x1
+
+    def ours():
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = conv1x1.conv1x1(xr, wr)
+        y.backward(dy)
+        return y.detach(), xr.grad, wr.grad
+
+    def stock():
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = F.conv2d(xr, wr)
+        y.backward(dy)
+        return y.detach(), xr.grad, wr.grad
+    a, b, t = ours(), ours(), stock()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    for u, v, name in zip(a, t, ("y", "dx", "dw")):
+        scale = v.abs().max().item()
+        assert (u - v).abs().max().item() <= 2e-5 * scale, name
+    times = {}
+    for name, fn in (("hip", ours), ("torch", stock)):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        times[name] = e0.elapsed_time(e1) / 5
+    print("\nconv 128->128 over 8x2048x8 pixels, forward + both gradients (+2 clones): hip %.3f ms, torch %.3f ms"
+          % (times["hip"], times["torch"]))
+
+
+def test_conv_block_routes_recorded_layers_through_the_kernels(cuda):
+    """pytorch_utils.Conv2d (P2/pytorch_utils.py:170-199): with autograd recording, the bias-free 1x1 convolution
+    runs on csrc/conv1x1.hip and gives torch's gradients; a layer with a bias stays on torch."""
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pytorch_utils as pt
+    torch.manual_seed(3)
+    blk = pt.Conv2d(19, 16, bn=True).to(cuda).train()
+    x = torch.randn(2, 19, 64, 8, device=cuda, requires_grad=True)
+    seen = []
+    orig = pt._hip_conv.conv1x1
+    pt._hip_conv.conv1x1 = lambda *a: (seen.append(1), orig(*a))[1]
+    try:
+        y = blk(x)
+        y.square().sum().backward()
+        gx, gw = x.grad.clone(), blk.conv.weight.grad.clone()
+        assert seen == [1]
+        withbias = pt.Conv2d(19, 16, bn=False).to(cuda)
+        withbias(x)
+        assert seen == [1]
+    finally:
+        pt._hip_conv.conv1x1 = orig
+    old = pt._USE_HIP_CONV
+    pt._USE_HIP_CONV = "0"
+    try:
+        blk.zero_grad()
+        x.grad = None
+        blk2 = blk                                            # same parameters, torch convolution
+        y2 = blk2(x)
+        y2.square().sum().backward()
+    finally:
+        pt._USE_HIP_CONV = old
+    assert (y - y2).abs().max().item() <= 1e-5 * y2.abs().max().item()
+    assert (gx - x.grad).abs().max().item() <= 1e-4 * x.grad.abs().max().item()
+    assert (gw - blk.conv.weight.grad).abs().max().item() <= 1e-4 * blk.conv.weight.grad.abs().max().item()
