@@ -211,20 +211,23 @@ __global__ __launch_bounds__(CONV_THREADS) void conv1x1_wgrad_kernel(int B, int 
   }
 }
 
-// dw[e] = sum over the partial rows, in row order (fixed summation order).
-__global__ void conv1x1_wgrad_reduce_kernel(int n, int nparts, const float *__restrict__ partial, float *__restrict__ dw) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int q = 0;
-  for (; q + 4 <= nparts; q += 4) {
-    s0 += partial[(size_t)q * n + e];
-    s1 += partial[(size_t)(q + 1) * n + e];
-    s2 += partial[(size_t)(q + 2) * n + e];
-    s3 += partial[(size_t)(q + 3) * n + e];
+// dw[e] = sum over the partial rows in a fixed order: 16 row groups per element (rows q = rg, rg + 16, ...), each
+// summed in row order, then combined by a fixed binary tree.  Block = 32 elements x 16 row groups.
+__global__ __launch_bounds__(512) void conv1x1_wgrad_reduce_kernel(int n, int nparts, const float *__restrict__ partial,
+                                                                  float *__restrict__ dw) {
+  __shared__ float part[16][33];
+  const int el = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  float s = 0.f;
+  if (e < n)
+    for (int q = rg; q < nparts; q += 16) s += partial[(size_t)q * n + e];
+  part[rg][el] = s;
+  __syncthreads();
+  for (int half = 8; half >= 1; half >>= 1) {
+    if (rg < half) part[rg][el] += part[rg + half][el];
+    __syncthreads();
   }
-  for (; q < nparts; ++q) s0 += partial[(size_t)q * n + e];
-  dw[e] = (s0 + s1) + (s2 + s3);
+  if (rg == 0 && e < n) dw[e] = part[0][el];
 }
 
 static int conv_grid_x() {
@@ -357,6 +360,6 @@ extern "C" void conv1x1_wgrad_kernel_wrapper(int b, int cin, int cout, int p, co
   else PWCLO_WGRAD_LAUNCH(12);
 #undef PWCLO_WGRAD_LAUNCH
   const int n = cin * cout;
-  hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, n, pl.grid * pl.ph, partial, dw);
+  hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(ceil_div(n, 32)), dim3(512), 0, st, n, pl.grid * pl.ph, partial, dw);
   check_launch("conv1x1_wgrad");
 }

@@ -143,11 +143,14 @@ class PointnetSAModulePWCLONet(nn.Module):
         mlp_spec[0] += 3
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn, init=torch.nn.init.xavier_uniform_)
 
-    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor]
+    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor], new_xyz: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor]:
-        """xyz (B,N,3), features (B,C,N) or None -> new_xyz (B,npoint,3), (B,mlp[-1],npoint)."""
+        """xyz (B,N,3), features (B,C,N) or None -> new_xyz (B,npoint,3), (B,mlp[-1],npoint).
+        ``new_xyz`` (not in the reference's signature): the layer's own samples when the caller has already drawn
+        them (pointnet2_utils.sample_and_gather_pair samples both frames of a pair in one launch)."""
         xyz_flipped = xyz.transpose(1, 2).contiguous()
-        new_xyz = pointnet2_utils.sample_and_gather(xyz, self.npoint)   # == furthest_point_sample + gather_operation
+        if new_xyz is None:
+            new_xyz = pointnet2_utils.sample_and_gather(xyz, self.npoint)   # == furthest_point_sample + gather_operation
         _, idx_q = pt_utils.knn_point(self.nsample, xyz, new_xyz)
         grouped_xyz = pointnet2_utils.grouping_operation(xyz_flipped, idx_q)
         xyz_diff = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)

@@ -61,6 +61,23 @@ def sample_and_gather(xyz, npoint):
     return new_xyz
 
 
+def sample_and_gather_pair(xyz_a, xyz_b, npoint):
+    """``sample_and_gather`` of two batches of clouds of the same shape in ONE sampler launch (the sampler runs one
+    workgroup per cloud: B clouds use B of the 256 compute units, so the two frames of a pair sampled together take
+    the time of one).  Returns ``(new_a, new_b)``, each identical to its own ``sample_and_gather`` call and carrying
+    its own rows of the sampling-chain record.  Falls back to two calls when the shapes differ."""
+    if xyz_a.shape != xyz_b.shape or not xyz_a.is_cuda or xyz_a.requires_grad or xyz_b.requires_grad:
+        return sample_and_gather(xyz_a, npoint), sample_and_gather(xyz_b, npoint)
+    B = xyz_a.shape[0]
+    both = sample_and_gather(torch.cat((xyz_a, xyz_b), dim=0).contiguous(), npoint)
+    rec = getattr(both, _CHAIN_ATTR, None)
+    new_a, new_b = both[:B], both[B:]
+    if rec is not None:
+        setattr(new_a, _CHAIN_ATTR, (rec[0][:B], rec[1], new_a._version))
+        setattr(new_b, _CHAIN_ATTR, (rec[0][B:], rec[1], new_b._version))
+    return new_a, new_b
+
+
 _DETERMINISTIC = None
 
 

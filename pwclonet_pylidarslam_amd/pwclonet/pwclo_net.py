@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..pointnet2_ops import pointnet2_utils
 from ..pointnet2_ops.pointnet2_modules import PointnetSAModulePWCLONet
 from .costvolume import CostVolume
 from .flowpredictor import FlowPredictor
@@ -168,11 +169,11 @@ class PWCLONet(nn.Module):
         self._fused = None
         return super().load_state_dict(*args, **kwargs)
 
-    def _pyramid(self, xyz_t, points):
+    def _pyramid(self, xyz_t, points, first_samples=None):
         levels = []
         x, f = xyz_t, points
-        for sa in (self.psa_1, self.psa_2, self.psa_3, self.psa_4):
-            x, f = sa(x, f)
+        for k, sa in enumerate((self.psa_1, self.psa_2, self.psa_3, self.psa_4)):
+            x, f = sa(x, f, new_xyz=first_samples) if (k == 0 and first_samples is not None) else sa(x, f)
             levels.append((x, f))
         return levels
 
@@ -198,8 +199,15 @@ class PWCLONet(nn.Module):
             l1 = [(x[:B], f[:B]) for x, f in both]
             l2 = [(x[B:], f[B:]) for x, f in both]
         else:
-            l1 = self._pyramid(cf(xyz_f1), points_f1)
-            l2 = self._pyramid(cf(xyz_f2), points_f2)
+            # train mode: BatchNorm statistics are per frame, so the pyramids run one after the other -- but the first
+            # level's sampling (the longest serial kernel of the step, one workgroup per cloud) is drawn for both
+            # frames in one launch
+            c1, c2 = cf(xyz_f1), cf(xyz_f2)
+            s1 = s2 = None
+            if xyz_f1.is_cuda and xyz_f1.shape == xyz_f2.shape and not (xyz_f1.requires_grad or xyz_f2.requires_grad):
+                s1, s2 = pointnet2_utils.sample_and_gather_pair(c1, c2, self.psa_1.npoint)
+            l1 = self._pyramid(c1, points_f1, s1)
+            l2 = self._pyramid(c2, points_f2, s2)
         (x11t, p11), (x12t, p12), (x13t, p13), (_x14t, p14) = l1
         (x21t, p21), (x22t, p22), (x23t, p23), _ = l2
         x11, x12, x13 = cf(x11t), cf(x12t), cf(x13t)

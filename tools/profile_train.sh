@@ -13,6 +13,6 @@ rows = list(csv.DictReader(open(f)))
 steps = 5
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("kernel time per step: %.2f ms" % (tot / 1e6 / steps))
-for r in rows[:30]:
+for r in rows[:45]:
     print(r["Name"][:100].ljust(100), r["Calls"].rjust(6), "%8.2f ms/step" % (float(r["TotalDurationNs"]) / 1e6 / steps), r["Percentage"])
 PY
