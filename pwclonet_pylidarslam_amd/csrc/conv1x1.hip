@@ -21,113 +21,163 @@ typedef float cv_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int CONV_THREADS = 512;            // 8 waves: 2 per SIMD
 constexpr int CONV_WAVES = CONV_THREADS / WAVE;
 constexpr int CONV_MAX_NBO = 8;              // 16-channel output blocks per workgroup (128 accumulator VGPRs)
+constexpr int CONV_AHEAD = 4;               // channel blocks in flight per wave (forward / input gradient)
 constexpr int WGRAD_MAXV = 7;                // float4 per thread of one staged weight-gradient chunk
 
 // y[b][co][p] = sum_ci W(co, ci) x[b][ci][p], W(co, ci) = w[co * w_ld_o + ci * w_ld_i]  (strides: the same kernel
 // computes the input gradient with the transposed view).  P % 4 == 0, rows 16-byte aligned.
 // grid (x = persistent tile workers, y = groups of NBO output blocks); dynamic LDS = NBO * nbi KiB.
 template <int NBO>
-__global__ __launch_bounds__(CONV_THREADS) void conv1x1_kernel(int B, int Cin, int Cout, int P, int nbi,
+__global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kernel(int B, int Cin, int Cout, int P, int nbi,
                                                               long long w_ld_o, long long w_ld_i,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y) {
   extern __shared__ float4 conv_w[];         // [NBO][nbi][64 lanes] : the 4 k-steps of one (o, m) tile per lane
   const int ob0 = blockIdx.y * NBO;
-  for (int e = threadIdx.x; e < NBO * nbi * WAVE; e += CONV_THREADS) {
-    const int lane = e & 63, om = e >> 6;
-    const int o = om / nbi, m = om - o * nbi;
-    const int co = 16 * (ob0 + o) + (lane & 15), g = lane >> 4;
-    float v[4];
+  {
+    // pack: zero the padding, then walk the stored matrix in memory order (coalesced) and scatter into operand order
+    float *wf = reinterpret_cast<float *>(conv_w);
+    for (int e = threadIdx.x; e < NBO * nbi * WAVE; e += CONV_THREADS) conv_w[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const bool tr = (w_ld_o == 1);           // stored (Cin, Cout) row-major: the input-gradient view
+    const int rows = tr ? Cin : Cout, cols = tr ? Cout : Cin;
+    for (int e0 = threadIdx.x; e0 < rows * cols; e0 += 8 * CONV_THREADS) {
+      float v[8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int ci = 16 * m + 4 * s + g;
-      v[s] = (co < Cout && ci < Cin) ? w[co * w_ld_o + ci * w_ld_i] : 0.f;
+      for (int u = 0; u < 8; ++u) {          // 8 independent loads in flight, then the scatter
+        const int e = e0 + u * CONV_THREADS;
+        v[u] = e < rows * cols ? w[e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * CONV_THREADS;
+        if (e < rows * cols) {
+          const int r = e / cols, c = e - r * cols;
+          const int co = tr ? c : r, ci = tr ? r : c;
+          const int o = (co >> 4) - ob0;
+          if (o >= 0 && o < NBO) {
+            const int m = ci >> 4, s = (ci >> 2) & 3, gg = ci & 3;
+            wf[(((o * nbi + m) * WAVE) + gg * 16 + (co & 15)) * 4 + s] = v[u];
+          }
+        }
+      }
     }
-    conv_w[e] = make_float4(v[0], v[1], v[2], v[3]);
+    __syncthreads();
   }
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
-  const int tpb = (P + 63) >> 6;             // 64-pixel tiles per batch element
+  const int tpb = (P + 31) >> 5;             // 32-pixel tiles per batch element: lane (g, j) owns pixels 2j, 2j + 1
   const long long tiles = (long long)B * tpb;
-  for (long long t = (long long)blockIdx.x * CONV_WAVES + wave; t < tiles; t += (long long)gridDim.x * CONV_WAVES) {
-    const int b = (int)(t / tpb);
-    const int px = ((int)(t - (long long)b * tpb) << 6) + 4 * j;
-    const bool pv = px < P;
-    const float *xb = x + (long long)b * Cin * P + px;
-    cv_f32x4 acc[NBO][4];
-#pragma unroll
-    for (int o = 0; o < NBO; ++o)
-#pragma unroll
-      for (int p = 0; p < 4; ++p) acc[o][p] = cv_f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 xa[4], xn[4];
-    auto load = [&](int m, float4(&d)[4]) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int c = 16 * m + 4 * s + g;
-        d[s] = (pv && c < Cin) ? *reinterpret_cast<const float4 *>(xb + (long long)c * P) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    auto mac = [&](int m, const float4(&d)[4]) {
-#pragma unroll
-      for (int o = 0; o < NBO; ++o) {
-        const float4 a = conv_w[(o * nbi + m) * WAVE + lane];
-        const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc[o][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], d[s].x, acc[o][0], 0, 0, 0);
-          acc[o][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], d[s].y, acc[o][1], 0, 0, 0);
-          acc[o][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], d[s].z, acc[o][2], 0, 0, 0);
-          acc[o][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], d[s].w, acc[o][3], 0, 0, 0);
-        }
-      }
-    };
-    load(0, xa);
-    for (int m = 0; m < nbi; m += 2) {
-      if (m + 1 < nbi) load(m + 1, xn);
-      mac(m, xa);
-      if (m + 1 < nbi) {
-        if (m + 2 < nbi) load(m + 2, xa);
-        mac(m + 1, xn);
-      }
+  const long long tstep = (long long)gridDim.x * CONV_WAVES;
+  const long long t0 = (long long)blockIdx.x * CONV_WAVES + wave;
+  if (t0 >= tiles) return;
+  // The wave's work is one stream of (tile, 16-channel block) steps.  A load cursor runs CONV_AHEAD steps ahead of
+  // the multiply cursor through a ring of register buffers, so a block has CONV_AHEAD multiply steps (of this wave
+  // and of the waves sharing its SIMD) to arrive from HBM -- tile boundaries included.
+  struct Cursor { long long t; int m; const float *xb; long long yoff; bool pv; };
+  auto locate = [&](Cursor &c) {
+    const int b = (int)(c.t / tpb);
+    const int px = ((int)(c.t - (long long)b * tpb) << 5) + 2 * j;
+    c.pv = c.t < tiles && px < P;
+    c.xb = x + (long long)b * Cin * P + px;
+    c.yoff = (long long)b * Cout * P + px;
+  };
+  auto advance = [&](Cursor &c) {
+    if (++c.m == nbi) {
+      c.m = 0;
+      c.t += tstep;
+      locate(c);
     }
-    if (pv) {
-      float *yb = y + (long long)b * Cout * P + px;
+  };
+  float2 ring[CONV_AHEAD][4];
+  auto load = [&](const Cursor &c, float2(&d)[4]) {
 #pragma unroll
-      for (int o = 0; o < NBO; ++o)
+    for (int s = 0; s < 4; ++s) {
+      const int ch = 16 * c.m + 4 * s + g;
+      d[s] = (c.pv && ch < Cin) ? *reinterpret_cast<const float2 *>(c.xb + (long long)ch * P) : make_float2(0.f, 0.f);
+    }
+  };
+  Cursor lc{t0, 0, nullptr, 0, false}, mc{t0, 0, nullptr, 0, false};
+  locate(lc);
+  locate(mc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = 16 * (ob0 + o) + 4 * g + r;
-          if (co < Cout)
-            *reinterpret_cast<float4 *>(yb + (long long)co * P) =
-                make_float4(acc[o][0][r], acc[o][1][r], acc[o][2][r], acc[o][3][r]);
+  for (int u = 0; u < CONV_AHEAD; ++u) {
+    load(lc, ring[u]);
+    advance(lc);
+  }
+  cv_f32x4 acc[NBO][2];
+#pragma unroll
+  for (int o = 0; o < NBO; ++o) acc[o][0] = acc[o][1] = cv_f32x4{0.f, 0.f, 0.f, 0.f};
+  while (mc.t < tiles) {
+#pragma unroll
+    for (int u = 0; u < CONV_AHEAD; ++u) {
+      if (mc.t < tiles) {                    // wave-uniform
+#pragma unroll
+        for (int o = 0; o < NBO; ++o) {
+          const float4 a = conv_w[(o * nbi + mc.m) * WAVE + lane];
+          const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc[o][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], ring[u][s].x, acc[o][0], 0, 0, 0);
+            acc[o][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], ring[u][s].y, acc[o][1], 0, 0, 0);
+          }
         }
+        load(lc, ring[u]);                   // the slot just consumed takes the step CONV_AHEAD ahead
+        advance(lc);
+        if (mc.m == nbi - 1) {
+          if (mc.pv) {
+            float *yb = y + mc.yoff;
+#pragma unroll
+            for (int o = 0; o < NBO; ++o)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int co = 16 * (ob0 + o) + 4 * g + r;
+                if (co < Cout) *reinterpret_cast<float2 *>(yb + (long long)co * P) = make_float2(acc[o][0][r], acc[o][1][r]);
+              }
+          }
+#pragma unroll
+          for (int o = 0; o < NBO; ++o) acc[o][0] = acc[o][1] = cv_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        advance(mc);
+      }
     }
   }
 }
 
 // dW(co, ci) partial sums of one workgroup over its pixel chunks.  Chunk = CP pixels of one batch element (CP a
 // multiple of 32, runtime): rows of dY (Cout) and X (Cin) staged in LDS with a row stride of CP + 4 floats (the
-// 16 rows of an operand read then fall into 16 different bank groups).  Waves: `ph` pixel phases x `tgw` tile
-// workers (ph * tgw = 8); wave (phase, tw) accumulates tiles tw, tw + tgw, ... over the 16-pixel sub-chunks
-// phase, phase + ph, ...; it writes its sums as partial row (blockIdx.x * ph + phase).
-template <int MAXT>
-__global__ __launch_bounds__(CONV_THREADS) void conv1x1_wgrad_kernel(int B, int Cin, int Cout, int P, int CP, int ph,
-                                                                    const float *__restrict__ dy,
-                                                                    const float *__restrict__ x,
-                                                                    float *__restrict__ partial) {
+// 16 rows of an operand read then fall into 16 different bank groups).  Waves: `ph` pixel phases x (wo x wm) tile
+// workers (ph * wo * wm = 8); worker (a, c) owns the RO x RM rectangle of 16x16 tiles {(a + wo * r, c + wm * q)}
+// -- RO + RM operand reads feed RO * RM * 4 MFMAs per 16 pixels -- over the 16-pixel sub-chunks phase, phase + ph,
+// ...; the phases are summed in LDS and the workgroup writes partial row blockIdx.x.
+template <int RO, int RM>
+__global__ __launch_bounds__(CONV_THREADS, (RO * RM <= 2 ? 4 : 2)) void conv1x1_wgrad_kernel(
+    int B, int Cin, int Cout, int P, int CP, int ph, int wo, int wm, const float *__restrict__ dy,
+    const float *__restrict__ x, float *__restrict__ partial) {
   extern __shared__ float conv_s[];          // [2][(Cout + Cin) rows][CP + 4]
   const int rows = Cout + Cin, ld = CP + 4;
-  const int nbo = (Cout + 15) >> 4, nbi = (Cin + 15) >> 4, ntiles = nbo * nbi;
+  const int nbo = (Cout + 15) >> 4, nbi = (Cin + 15) >> 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, i = lane & 15;
-  const int tgw = CONV_WAVES / ph, phase = wave / tgw, tw = wave - phase * tgw;
+  const int tgw = wo * wm, phase = wave / tgw, tw = wave - phase * tgw;
+  const int wa = tw / wm, wc = tw - wa * wm;
   const int cpb = (P + CP - 1) / CP;         // chunks per batch element
   const long long chunks = (long long)B * cpb;
   const int vec = CP >> 2;                   // float4 per staged row
-  cv_f32x4 acc[MAXT];
+  cv_f32x4 acc[RO][RM];
+  int aoff[RO], boff[RM];                    // LDS offsets of this lane's operand rows, -1 = padding row / no tile
 #pragma unroll
-  for (int t = 0; t < MAXT; ++t) acc[t] = cv_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < RO; ++r) {
+    const int ro = 16 * (wa + wo * r) + i;
+    aoff[r] = (wa + wo * r < nbo && ro < Cout) ? ro * ld + 4 * g : -1;
+#pragma unroll
+    for (int q = 0; q < RM; ++q) acc[r][q] = cv_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int q = 0; q < RM; ++q) {
+    const int rm = 16 * (wc + wm * q) + i;
+    boff[q] = (wc + wm * q < nbi && rm < Cin) ? (Cout + rm) * ld + 4 * g : -1;
+  }
 
   float4 pre[WGRAD_MAXV];                   // the next chunk on its way from HBM while this one is multiplied
   auto fetch = [&](long long c) {
@@ -171,44 +221,52 @@ __global__ __launch_bounds__(CONV_THREADS) void conv1x1_wgrad_kernel(int B, int 
     const long long cn = c + gridDim.x;
     if (cn < chunks) fetch(cn);
     const float *sd = conv_s + (size_t)buf * rows * ld;
-    const float *sx = sd + (size_t)Cout * ld;
     for (int sc = phase; sc < (CP >> 4); sc += ph) {
-      const int off = 16 * sc + 4 * g;
+      const float *sp = sd + 16 * sc;
+      float4 av[RO], bv[RM];
 #pragma unroll
-      for (int t = 0; t < MAXT; ++t) {
-        const int tile = tw + t * tgw;
-        if (tile < ntiles) {
-          const int o = tile / nbi, m = tile - o * nbi;
-          const int ro = 16 * o + i, rm = 16 * m + i;
-          const float4 a = (ro < Cout) ? *reinterpret_cast<const float4 *>(sd + (size_t)ro * ld + off)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float4 bq = (rm < Cin) ? *reinterpret_cast<const float4 *>(sx + (size_t)rm * ld + off)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[t], 0, 0, 0);
+      for (int r = 0; r < RO; ++r)
+        av[r] = aoff[r] >= 0 ? *reinterpret_cast<const float4 *>(sp + aoff[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < RM; ++q)
+        bv[q] = boff[q] >= 0 ? *reinterpret_cast<const float4 *>(sp + boff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < RO; ++r)
+#pragma unroll
+        for (int q = 0; q < RM; ++q) {
+          acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].x, bv[q].x, acc[r][q], 0, 0, 0);
+          acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].y, bv[q].y, acc[r][q], 0, 0, 0);
+          acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].z, bv[q].z, acc[r][q], 0, 0, 0);
+          acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].w, bv[q].w, acc[r][q], 0, 0, 0);
         }
-      }
     }
     if (cn < chunks) put(buf ^ 1);          // the other buffer was last read before the previous barrier
     __syncthreads();
     buf ^= 1;
   }
-  float *out = partial + ((size_t)blockIdx.x * ph + phase) * Cout * Cin;
+  if (ph > 1) {
+    // the pixel phases of a tile are summed here, in phase order (ph > 1 only for <= 4 tiles of one per worker)
+    cv_f32x4 *red = reinterpret_cast<cv_f32x4 *>(conv_s);   // the staging buffers are free after the loop's last barrier
+    red[(phase * tgw + tw) * WAVE + lane] = acc[0][0];
+    __syncthreads();
+    if (phase != 0) return;
+    for (int q = 1; q < ph; ++q) acc[0][0] += red[(q * tgw + tw) * WAVE + lane];
+  }
+  float *out = partial + (size_t)blockIdx.x * Cout * Cin;
 #pragma unroll
-  for (int t = 0; t < MAXT; ++t) {
-    const int tile = tw + t * tgw;
-    if (tile < ntiles) {
-      const int o = tile / nbi, m = tile - o * nbi;
-      const int ci = 16 * m + i;
+  for (int r = 0; r < RO; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = 16 * o + 4 * g + r;
-        if (co < Cout && ci < Cin) out[(size_t)co * Cin + ci] = acc[t][r];
+    for (int q = 0; q < RM; ++q) {
+      const int o = wa + wo * r, m = wc + wm * q;
+      if (o < nbo && m < nbi) {
+        const int ci = 16 * m + i;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int co = 16 * o + 4 * g + k;
+          if (co < Cout && ci < Cin) out[(size_t)co * Cin + ci] = acc[r][q][k];
+        }
       }
     }
-  }
 }
 
 // dw[e] = sum over the partial rows in a fixed order: 16 row groups per element (rows q = rg, rg + 16, ...), each
@@ -241,13 +299,30 @@ static int conv_grid_x() {
   return cus;
 }
 
-struct WgradPlan { int cp, ph, grid; size_t lds; };
+struct WgradPlan { int cp, ph, wo, wm, ro, rm, grid; size_t lds; };
 
+// Split of the 8 waves: `ph` pixel phases when there are fewer than 5 tiles (one tile per worker then), else
+// wo x wm = 8 workers over the (nbo, nbi) tile grid with the fewest operand reads per MFMA; ro in {1,2,4},
+// rm in {1,2,3,4} (the instantiated rectangles).  ro = 0: not covered.
 static WgradPlan wgrad_plan(int b, int cin, int cout, int p) {
   WgradPlan pl;
   const int rows = cin + cout;
-  const int ntiles = ceil_div(cout, 16) * ceil_div(cin, 16);
+  const int nbo = ceil_div(cout, 16), nbi = ceil_div(cin, 16), ntiles = nbo * nbi;
   pl.ph = ntiles >= 5 ? 1 : ntiles >= 3 ? 2 : ntiles == 2 ? 4 : 8;
+  const int tgw = CONV_WAVES / pl.ph;
+  pl.wo = pl.wm = pl.ro = pl.rm = 0;
+  int best = 1 << 30;
+  for (int wo = 1; wo <= tgw; wo *= 2) {
+    const int wm = tgw / wo;
+    int ro = ceil_div(nbo, wo), rm = ceil_div(nbi, wm);
+    ro = ro <= 2 ? ro : ro <= 4 ? 4 : 99;
+    if (ro > 4 || rm > 4 || (pl.ph > 1 && ro * rm != 1)) continue;
+    const int cost = ro * rm * 16 + ro + rm;      // MFMA slots per wave (padding tiles cost time) first, then operand reads
+    if (cost < best) {
+      best = cost;
+      pl.wo = wo; pl.wm = wm; pl.ro = ro; pl.rm = rm;
+    }
+  }
   // chunk: as many pixels as keep the double-buffered stage under ~96 KiB, 32..512, no longer than a row
   int cp = 512;
   while (cp > 32 && (size_t)2 * rows * (cp + 4) * 4 > (size_t)96 * 1024) cp >>= 1;
@@ -256,8 +331,9 @@ static WgradPlan wgrad_plan(int b, int cin, int cout, int p) {
   pl.cp = cp;
   pl.lds = (size_t)2 * rows * (cp + 4) * 4;
   const long long chunks = (long long)b * ceil_div(p, cp);
-  const int cus = conv_grid_x();
-  pl.grid = (int)(chunks < cus ? chunks : cus);
+  const int per_cu = ((size_t)2 * pl.lds <= (size_t)150 * 1024 && pl.ro * pl.rm <= 2) ? 2 : 1;
+  const long long want = (long long)conv_grid_x() * per_cu;
+  pl.grid = (int)(chunks < want ? chunks : want);
   return pl;
 }
 
@@ -301,8 +377,8 @@ extern "C" void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, 
   const int nbo = ceil_div(nbo_all, gy);
   const size_t lds = (size_t)nbo * nbi * WAVE * sizeof(float4);
   PWCLO_REQUIRE(lds <= 150 * 1024, "conv1x1_forward: cin=%d cout=%d need %zu bytes of LDS for the weights", cin, cout, lds);
-  const long long tiles = (long long)b * ceil_div(p, 64);
-  const int per_cu = lds <= 72 * 1024 ? 2 : 1;                          // workgroups a CU can hold
+  const long long tiles = (long long)b * ceil_div(p, 32);
+  const int per_cu = (lds <= 72 * 1024 && nbo <= 3) ? 2 : 1;             // workgroups a CU can hold (LDS, registers)
   long long gx = (long long)conv_grid_x() * per_cu / gy;
   const long long need = (tiles + CONV_WAVES - 1) / CONV_WAVES;
   if (gx > need) gx = need;
@@ -332,7 +408,7 @@ extern "C" void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, 
 extern "C" long long conv1x1_wgrad_workspace_bytes(int b, int cin, int cout, int p) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0) return 0;
   const WgradPlan pl = wgrad_plan(b, cin, cout, p);
-  return (long long)pl.grid * pl.ph * cin * cout * (long long)sizeof(float);
+  return (long long)pl.grid * cin * cout * (long long)sizeof(float);
 }
 
 extern "C" void conv1x1_wgrad_kernel_wrapper(int b, int cin, int cout, int p, const float *dy, const float *x,
@@ -345,21 +421,19 @@ extern "C" void conv1x1_wgrad_kernel_wrapper(int b, int cin, int cout, int p, co
                 "conv1x1_wgrad: cin=%d cout=%d: chunk of %d pixels exceeds the staging registers", cin, cout, pl.cp);
   hipStream_t st = current_stream();
   float *partial = reinterpret_cast<float *>(workspace);
-  const int per = ceil_div(ceil_div(cout, 16) * ceil_div(cin, 16), CONV_WAVES / pl.ph);
-  PWCLO_REQUIRE(per <= 12, "conv1x1_wgrad: cin=%d cout=%d: %d 16x16 tiles per wave, at most 12", cin, cout, per);
-#define PWCLO_WGRAD_LAUNCH(T)                                                                                         \
-  do {                                                                                                                \
-    PWCLO_REQUIRE(allow_lds(conv1x1_wgrad_kernel<T>, pl.lds), "conv1x1_wgrad: cannot reserve %zu bytes of LDS", pl.lds); \
-    hipLaunchKernelGGL((conv1x1_wgrad_kernel<T>), dim3(pl.grid), dim3(CONV_THREADS), pl.lds, st, b, cin, cout, p,      \
-                       pl.cp, pl.ph, dy, x, partial);                                                                 \
-  } while (0)
-  if (per <= 1) PWCLO_WGRAD_LAUNCH(1);
-  else if (per <= 2) PWCLO_WGRAD_LAUNCH(2);
-  else if (per <= 4) PWCLO_WGRAD_LAUNCH(4);
-  else if (per <= 8) PWCLO_WGRAD_LAUNCH(8);
-  else PWCLO_WGRAD_LAUNCH(12);
+  PWCLO_REQUIRE(pl.ro > 0, "conv1x1_wgrad: cin=%d cout=%d: more than 4 x 4 tiles of 16 x 16 per wave", cin, cout);
+#define PWCLO_WGRAD_LAUNCH(R, M)                                                                                       \
+  if (pl.ro == R && pl.rm == M) {                                                                                      \
+    PWCLO_REQUIRE(allow_lds(conv1x1_wgrad_kernel<R, M>, pl.lds), "conv1x1_wgrad: cannot reserve %zu bytes of LDS",     \
+                  pl.lds);                                                                                             \
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<R, M>), dim3(pl.grid), dim3(CONV_THREADS), pl.lds, st, b, cin, cout, p,   \
+                       pl.cp, pl.ph, pl.wo, pl.wm, dy, x, partial);                                                    \
+  }
+  PWCLO_WGRAD_LAUNCH(1, 1) PWCLO_WGRAD_LAUNCH(1, 2) PWCLO_WGRAD_LAUNCH(1, 3) PWCLO_WGRAD_LAUNCH(1, 4)
+  PWCLO_WGRAD_LAUNCH(2, 1) PWCLO_WGRAD_LAUNCH(2, 2) PWCLO_WGRAD_LAUNCH(2, 3) PWCLO_WGRAD_LAUNCH(2, 4)
+  PWCLO_WGRAD_LAUNCH(4, 1) PWCLO_WGRAD_LAUNCH(4, 2) PWCLO_WGRAD_LAUNCH(4, 3) PWCLO_WGRAD_LAUNCH(4, 4)
 #undef PWCLO_WGRAD_LAUNCH
   const int n = cin * cout;
-  hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(ceil_div(n, 32)), dim3(512), 0, st, n, pl.grid * pl.ph, partial, dw);
+  hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(ceil_div(n, 32)), dim3(512), 0, st, n, pl.grid, partial, dw);
   check_launch("conv1x1_wgrad");
 }

@@ -352,3 +352,24 @@ def test_training_unit_parameter_count():
                                                          loss_option="l2_norm", nb_levels=4, scalar_last=False)))
     assert gradient_bucket_values(unit) == 775068 + 2
     assert sorted(k for k in unit.state_dict() if "s_param" in k) == ["loss_module.exp_weighting.s_param"]
+
+
+def test_pointwise_conv_shapes_of_the_network_are_the_tested_ones():
+    """tests/test_gpu_conv.py checks csrc/conv1x1.hip on NET_SHAPES: that list is every bias-free 1x1 Conv2d of the
+    network (P2/pytorch_utils.py:170-199 inside the SharedMLPs); layers with a bias (the pose heads' Conv1d) stay
+    on torch."""
+    import importlib.util
+    import torch
+    from pwclonet_pylidarslam_amd.pwclonet import PWCLONet
+    spec = importlib.util.spec_from_file_location("tgc", os.path.join(os.path.dirname(__file__), "test_gpu_conv.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device="cpu", scalar_last=False, log_mode="none"))
+    shapes = set()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            assert m.bias is None and m.kernel_size == (1, 1)
+            shapes.add((m.in_channels, m.out_channels))
+        elif isinstance(m, torch.nn.Conv1d):
+            assert m.bias is not None
+    assert shapes == set(mod.NET_SHAPES)
