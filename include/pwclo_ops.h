@@ -311,6 +311,25 @@ void batchnorm_train_backward_kernel_wrapper(int b, int c, int l, const float *x
                                              const float *save_invstd, float *dx, float *dgamma, float *dbeta,
                                              void *workspace, int relu);
 
+/* Tail of the module path's grouped stacks in training mode: BatchNorm (batch statistics) -> ReLU -> max over the k
+ * neighbours (P2/pointnet2_modules.py: `self.mlp_module(new_features)` followed by `.max(dim=3)` /
+ * F.max_pool2d(kernel=[1, nsample]); the reference materialises the (b, c, s, k) activation between them).
+ * x (b, c, s, k) f32 = the last convolution's output, k in {4, 8, 16, 32}; pooled (b, c, s) f32; arg (b, c, s) u8 =
+ * first neighbour reaching the maximum; xsel (b, c, s) f32 = x at arg.  Statistics, running_* update, save_* and
+ * workspace as batchnorm_train_forward_kernel_wrapper.  Same values as BN -> ReLU -> max evaluated separately. */
+void batchnorm_train_relu_maxk_forward_kernel_wrapper(int b, int c, int s, int k, const float *x, const float *gamma,
+                                                      const float *beta, float eps, float momentum,
+                                                      float *running_mean, float *running_var, float *pooled,
+                                                      unsigned char *arg, float *xsel, float *save_mean,
+                                                      float *save_invstd, void *workspace);
+/* dx (b, c, s, k), dgamma (c), dbeta (c) from dpool (b, c, s), the gradient w.r.t. pooled: the dense gradient of the
+ * activation (dpool at arg where the pooled value was positive, 0 elsewhere) is never written. */
+void batchnorm_train_relu_maxk_backward_kernel_wrapper(int b, int c, int s, int k, const float *x, const float *dpool,
+                                                       const unsigned char *arg, const float *xsel,
+                                                       const float *gamma, const float *beta, const float *save_mean,
+                                                       const float *save_invstd, float *dx, float *dgamma,
+                                                       float *dbeta, void *workspace);
+
 /* Pointwise convolution of the module path's shared MLPs, forward and both gradients, on channel-major rows
  * (P2/pytorch_utils.py:114-167: Conv2d(kernel_size=(1,1), bias=False) inside SharedMLP, pytorch_utils.py:12-37;
  * the reference runs torch.nn.Conv2d = cuDNN there).  x (b, cin, p), y (b, cout, p), p = product of the trailing

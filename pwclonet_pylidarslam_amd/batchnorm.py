@@ -68,3 +68,55 @@ def batch_norm_train(x, bn, relu=False):
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu)
+
+
+class _BatchNormReluMaxK(Function):
+    """BatchNorm (batch statistics) -> ReLU -> max over the last dimension of x (B, C, S, K), the tail of the grouped
+    stacks (P2/pointnet2_modules.py: SharedMLP followed by ``.max(dim=3)``), without the (B, C, S, K) activation:
+    the forward keeps the arg-max and the selected inputs, the backward rebuilds the sparse gradient from them."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        x = x.contiguous()
+        B, C, S, K = x.shape
+        pooled = torch.empty((B, C, S), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, C, S), dtype=torch.uint8, device=x.device)
+        xsel = torch.empty((B, C, S), dtype=torch.float32, device=x.device)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = _workspace(C, x.device)
+        p = lambda t: t.data_ptr() if t is not None else 0
+        _lib.call("batchnorm_train_relu_maxk_forward_kernel_wrapper", x.device, B, C, S, K, p(x), p(weight), p(bias),
+                  float(eps), float(momentum), p(running_mean), p(running_var), p(pooled), p(arg), p(xsel), p(save_mean),
+                  p(save_invstd), p(ws))
+        ctx.save_for_backward(x, weight, bias, save_mean, save_invstd, arg, xsel)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpool):
+        x, weight, bias, save_mean, save_invstd, arg, xsel = ctx.saved_tensors
+        dpool = dpool.contiguous()
+        B, C, S, K = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = _workspace(C, x.device)
+        p = lambda t: t.data_ptr() if t is not None else 0
+        _lib.call("batchnorm_train_relu_maxk_backward_kernel_wrapper", x.device, B, C, S, K, p(x), p(dpool), p(arg),
+                  p(xsel), p(weight), p(bias), p(save_mean), p(save_invstd), p(dx), p(dgamma), p(dbeta), p(ws))
+        return (dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), None, None, None,
+                None)
+
+
+def supported_maxk(x, bn):
+    return supported(x, bn) and x.dim() == 4 and x.shape[3] in (4, 8, 16, 32)
+
+
+def batch_norm_train_relu_max(x, bn):
+    """``relu(bn(x)).max(dim=3)[0]`` for the training-mode module ``bn`` and x (B, C, S, K): one statistics pass and one
+    pooled pass, nothing of shape (B, C, S, K) written."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BatchNormReluMaxK.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)

@@ -187,6 +187,91 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, floa
   }
 }
 
+// Tail of a grouped stack: BatchNorm -> ReLU -> max over the K neighbours, without writing the (B, C, S, K)
+// activation.  K in {4, 8, 16, 32}: K / 4 neighbouring lanes hold one row (a float4 each) and combine (value, first
+// index) pairs by shuffles.  Per row: pooled = max_k relu(bn(x_k)), arg = the first k reaching it, xsel = x at arg
+// (all the backward's reductions need, see batchnorm_train_relu_maxk_backward).
+template <int K>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_relu_maxk_kernel(int C, int S, const float *__restrict__ x,
+                                                                       const float *__restrict__ gamma,
+                                                                       const float *__restrict__ beta,
+                                                                       const float *__restrict__ mean,
+                                                                       const float *__restrict__ invstd,
+                                                                       float *__restrict__ pooled,
+                                                                       unsigned char *__restrict__ arg,
+                                                                       float *__restrict__ xsel) {
+  constexpr int LPR = K / 4;
+  const int ch = blockIdx.y, b = blockIdx.z;
+  const size_t plane = (size_t)b * C + ch;
+  const long long q = (long long)blockIdx.x * BN_THREADS + threadIdx.x;     // float4 index inside the (S, K) plane
+  if (q >= (long long)S * LPR) return;                                       // whole rows leave together (LPR | 64)
+  const int srow = (int)(q / LPR), part = (int)(q - (long long)srow * LPR);
+  const float mu = mean[ch], is = invstd[ch];
+  const float g = gamma != nullptr ? gamma[ch] : 1.f;
+  const float be = beta != nullptr ? beta[ch] : 0.f;
+  const float4 xv = *reinterpret_cast<const float4 *>(x + plane * (size_t)S * K + (size_t)q * 4);
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+  float best = -1.f, bx = 0.f;
+  int bi = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float yv = fmaxf((xs[e] - mu) * is * g + be, 0.f);
+    if (yv > best) { best = yv; bi = part * 4 + e; bx = xs[e]; }
+  }
+#pragma unroll
+  for (int off = 1; off < LPR; off <<= 1) {
+    const float ob = __shfl_xor(best, off, 64), ox = __shfl_xor(bx, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; bx = ox; }
+  }
+  if (part == 0) {
+    const size_t o = plane * (size_t)S + srow;
+    pooled[o] = best;
+    arg[o] = (unsigned char)bi;
+    xsel[o] = bx;
+  }
+}
+
+// dx of the tail above from the pooled gradient: dy is dpool at (row, arg) where the pooled value was positive and 0
+// elsewhere, never materialised; dx = gamma * invstd * (dy - dbeta / M - xhat * dgamma / M), M = B * S * K.
+template <int K>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_bwd_maxk_kernel(int C, int S, float inv_m,
+                                                                      const float *__restrict__ x,
+                                                                      const float *__restrict__ dpool,
+                                                                      const unsigned char *__restrict__ arg,
+                                                                      const float *__restrict__ gamma,
+                                                                      const float *__restrict__ beta,
+                                                                      const float *__restrict__ mean,
+                                                                      const float *__restrict__ invstd,
+                                                                      const float *__restrict__ dgamma,
+                                                                      const float *__restrict__ dbeta,
+                                                                      float *__restrict__ dx) {
+  constexpr int LPR = K / 4;
+  const int ch = blockIdx.y, b = blockIdx.z;
+  const size_t plane = (size_t)b * C + ch;
+  const long long q = (long long)blockIdx.x * BN_THREADS + threadIdx.x;
+  if (q >= (long long)S * LPR) return;
+  const int srow = (int)(q / LPR), part = (int)(q - (long long)srow * LPR);
+  const float mu = mean[ch], is = invstd[ch];
+  const float g = gamma != nullptr ? gamma[ch] : 1.f;
+  const float be = beta != nullptr ? beta[ch] : 0.f;
+  const float c0 = dbeta[ch] * inv_m, c1 = dgamma[ch] * inv_m;
+  const size_t o = plane * (size_t)S + srow;
+  const float gp = dpool[o];
+  const int sel = (int)arg[o] - part * 4;                                    // 0..3 when the selected neighbour is here
+  const size_t at = plane * (size_t)S * K + (size_t)q * 4;
+  const float4 xv = *reinterpret_cast<const float4 *>(x + at);
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+  float out[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float xh = (xs[e] - mu) * is;
+    const float gv = (e == sel && xh * g + be > 0.f) ? gp : 0.f;
+    out[e] = ((gv - c0) - xh * c1) * (g * is);
+  }
+  *reinterpret_cast<float4 *>(dx + at) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 static int bn_splits(int c, long long M, long long *per_split) {
   long long want = 2048 / (c > 0 ? c : 1);                       // ~2048 workgroups in the reduction passes
   if (want < 1) want = 1;
@@ -277,4 +362,77 @@ extern "C" void batchnorm_train_backward_kernel_wrapper(int b, int c, int l, con
   else
     bn_launch_apply<1, false>(vec, b, c, l, inv_m, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, dx, st);
   check_launch("batchnorm_train_backward");
+}
+
+// ---- BatchNorm -> ReLU -> max over K (tail of the grouped stacks) ------------------------------------------------
+#define PWCLO_BN_MAXK_DISPATCH(k, CALL) \
+  switch (k) {                          \
+    case 4: CALL(4); break;             \
+    case 8: CALL(8); break;             \
+    case 16: CALL(16); break;           \
+    default: CALL(32); break;           \
+  }
+
+extern "C" void batchnorm_train_relu_maxk_forward_kernel_wrapper(int b, int c, int s, int k, const float *x,
+                                                                 const float *gamma, const float *beta, float eps,
+                                                                 float momentum, float *running_mean,
+                                                                 float *running_var, float *pooled,
+                                                                 unsigned char *arg, float *xsel, float *save_mean,
+                                                                 float *save_invstd, void *workspace) {
+  if (b <= 0 || c <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k == 4 || k == 8 || k == 16 || k == 32, "batchnorm_train_relu_maxk_forward: k=%d not in {4,8,16,32}", k);
+  PWCLO_REQUIRE(b <= 65535 && c <= 65535, "batchnorm_train_relu_maxk_forward: b=%d c=%d exceed the grid limits", b, c);
+  PWCLO_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+                "batchnorm_train_relu_maxk_forward: running_mean and running_var must be given together%s", "");
+  PWCLO_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "batchnorm_train_relu_maxk_forward: x must be 16-byte aligned%s", "");
+  const int l = s * k;
+  const long long M = (long long)b * l;
+  long long per_split;
+  const int nsplit = bn_splits(c, M, &per_split);
+  double *partial = reinterpret_cast<double *>(workspace);
+  hipStream_t st = current_stream();
+  const float *none = nullptr;
+  hipLaunchKernelGGL((bn_partial_kernel<0, false>), dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x,
+                     none, none, none, none, none, partial);
+  hipLaunchKernelGGL(bn_forward_finish_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, st, c, nsplit, M, eps, momentum,
+                     partial, running_mean, running_var, save_mean, save_invstd);
+  const dim3 grid(ceil_div(l / 4, BN_THREADS), c, b);
+#define PWCLO_CALL(KK)                                                                                              \
+  hipLaunchKernelGGL((bn_apply_relu_maxk_kernel<KK>), grid, dim3(BN_THREADS), 0, st, c, s, x, gamma, beta, save_mean, \
+                     save_invstd, pooled, arg, xsel)
+  PWCLO_BN_MAXK_DISPATCH(k, PWCLO_CALL)
+#undef PWCLO_CALL
+  check_launch("batchnorm_train_relu_maxk_forward");
+}
+
+extern "C" void batchnorm_train_relu_maxk_backward_kernel_wrapper(int b, int c, int s, int k, const float *x,
+                                                                  const float *dpool, const unsigned char *arg,
+                                                                  const float *xsel, const float *gamma,
+                                                                  const float *beta, const float *save_mean,
+                                                                  const float *save_invstd, float *dx, float *dgamma,
+                                                                  float *dbeta, void *workspace) {
+  if (b <= 0 || c <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k == 4 || k == 8 || k == 16 || k == 32, "batchnorm_train_relu_maxk_backward: k=%d not in {4,8,16,32}", k);
+  PWCLO_REQUIRE(b <= 65535 && c <= 65535, "batchnorm_train_relu_maxk_backward: b=%d c=%d exceed the grid limits", b, c);
+  PWCLO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+                "batchnorm_train_relu_maxk_backward: x and dx must be 16-byte aligned%s", "");
+  // the reductions run over the selected elements only: (xsel, dpool) as a (b, c, s) problem of the dense kernel --
+  // every other element has dy = 0 and adds nothing to sum(dy) or sum(dy * xhat)
+  const long long Ms = (long long)b * s;
+  long long per_split;
+  const int nsplit = bn_splits(c, Ms, &per_split);
+  double *partial = reinterpret_cast<double *>(workspace);
+  hipStream_t st = current_stream();
+  hipLaunchKernelGGL((bn_partial_kernel<1, true>), dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, s, Ms, per_split, xsel,
+                     dpool, save_mean, save_invstd, gamma, beta, partial);
+  hipLaunchKernelGGL(bn_backward_finish_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, st, c, nsplit, partial, dgamma,
+                     dbeta);
+  const float inv_m = (float)(1.0 / ((double)b * s * k));
+  const dim3 grid(ceil_div(s * k / 4, BN_THREADS), c, b);
+#define PWCLO_CALL(KK)                                                                                               \
+  hipLaunchKernelGGL((bn_apply_bwd_maxk_kernel<KK>), grid, dim3(BN_THREADS), 0, st, c, s, inv_m, x, dpool, arg, gamma, \
+                     beta, save_mean, save_invstd, dgamma, dbeta, dx)
+  PWCLO_BN_MAXK_DISPATCH(k, PWCLO_CALL)
+#undef PWCLO_CALL
+  check_launch("batchnorm_train_relu_maxk_backward");
 }

@@ -47,8 +47,8 @@ class _PointnetSAModuleBase(nn.Module):
             new_xyz = pointnet2_utils.gather_operation(xyz_flipped, fps_idx).transpose(1, 2).contiguous()
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            new_features = mlp(grouper(xyz, new_xyz, features))       # (B, mlp[-1], npoint, nsample)
-            pooled.append(new_features.max(dim=3)[0])                 # == max_pool2d(kernel=[1,nsample]).squeeze(-1)
+            # (B, mlp[-1], npoint, nsample) -> max over nsample == max_pool2d(kernel=[1,nsample]).squeeze(-1)
+            pooled.append(pt_utils.shared_mlp_max(mlp, grouper(xyz, new_xyz, features)))
         return new_xyz, torch.cat(pooled, dim=1)
 
 
@@ -123,7 +123,7 @@ class PointnetLFPModuleMSG(nn.Module):
                 features1: torch.Tensor) -> torch.Tensor:
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            new_features = mlp(grouper(xyz1, xyz2, features1)).max(dim=3)[0]     # (B, mlp[-1], N2)
+            new_features = pt_utils.shared_mlp_max(mlp, grouper(xyz1, xyz2, features1))     # (B, mlp[-1], N2)
             if features2 is not None:
                 new_features = torch.cat([new_features, features2], dim=1)
             outs.append(self.post_mlp(new_features.unsqueeze(-1)))
@@ -159,8 +159,7 @@ class PointnetSAModulePWCLONet(nn.Module):
             new_features = torch.cat((xyz_diff, grouped_features), dim=1)
         else:
             new_features = torch.cat((xyz_diff, grouped_xyz), dim=1)
-        new_features = self.mlp_module(new_features)
-        new_features = new_features.max(dim=3)[0]  # == max_pool2d(kernel=[1,K]).squeeze(-1)
+        new_features = pt_utils.shared_mlp_max(self.mlp_module, new_features)  # mlp, then max_pool2d(kernel=[1,K])
         return new_xyz, new_features
 
 
@@ -192,8 +191,7 @@ class PointnetFPModulePWCLONet(nn.Module):
                 new_features = torch.cat((new_features, xyz_diff), dim=1)
         else:
             new_features = self.grouper(xyz1, xyz2, features1)
-        new_features = self.mlp(new_features)
-        new_features = new_features.max(dim=3)[0]
+        new_features = pt_utils.shared_mlp_max(self.mlp, new_features)
         if features2 is not None:
             new_features = torch.cat([new_features, features2], dim=1)
         new_features = self.post_mlp(new_features.unsqueeze(-1))

@@ -115,6 +115,24 @@ class _ConvBlock(nn.Sequential):
         return x
 
 
+def shared_mlp_max(mlp, x):
+    """``mlp(x).max(dim=3)[0]`` for a SharedMLP ``mlp`` on x (B, C, S, K) -- the tail every grouped stack of the
+    reference ends with (P2/pointnet2_modules.py: SA, set-upconv).  In training mode on the GPU the last layer's
+    BatchNorm, ReLU and the max run as one op (batchnorm.batch_norm_train_relu_max): same values, the largest
+    activation of the stack and its gradient are never written."""
+    layers = list(mlp)
+    mods = list(layers[-1]) if layers and isinstance(layers[-1], _ConvBlock) else []
+    if (_USE_HIP_BN and x.is_cuda and len(mods) == 3 and isinstance(mods[0], nn.Conv2d) and isinstance(mods[1], _BN)
+            and type(mods[2]) is nn.ReLU and mods[1][0].training):
+        for layer in layers[:-1]:
+            x = layer(x)
+        y = _conv(mods[0], x)
+        if _hip_bn.supported_maxk(y, mods[1][0]):
+            return _hip_bn.batch_norm_train_relu_max(y, mods[1][0])
+        return mods[2](mods[1](y)).max(dim=3)[0]
+    return mlp(x).max(dim=3)[0]
+
+
 class Conv1d(_ConvBlock):
     def __init__(self, in_size: int, out_size: int, *, kernel_size: int = 1, stride: int = 1,
                  padding=0, activation=nn.ReLU(inplace=True), bn: bool = False,

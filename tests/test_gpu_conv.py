@@ -144,3 +144,67 @@ def test_conv_block_routes_recorded_layers_through_the_kernels(cuda):
     assert (y - y2).abs().max().item() <= 1e-5 * y2.abs().max().item()
     assert (gx - x.grad).abs().max().item() <= 1e-4 * x.grad.abs().max().item()
     assert (gw - blk.conv.weight.grad).abs().max().item() <= 1e-4 * blk.conv.weight.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("B,C,S,K", [(2, 16, 64, 32), (3, 5, 36, 16), (1, 64, 256, 8), (2, 7, 12, 4), (4, 32, 1024, 32)])
+def test_bn_relu_max_tail_matches_the_three_separate_ops(cuda, B, C, S, K):
+    """csrc/batchnorm.hip tail (BatchNorm with batch statistics -> ReLU -> max over K) against torch's own three ops in
+    float64: pooled values, running statistics, and the gradients w.r.t. the input, gamma and beta.  Bound 1e-5 of each
+    tensor's scale (fp32 arithmetic with fp64 statistics against a float64 evaluation)."""
+    import torch.nn.functional as F
+    from pwclonet_pylidarslam_amd import batchnorm as hb
+    g = torch.Generator().manual_seed(B * 1000 + C * 10 + K)
+    x = (torch.randn(B, C, S, K, generator=g) * 1.7 + 0.3).to(cuda)
+    bn = torch.nn.BatchNorm2d(C).to(cuda).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    dpool = torch.randn(B, C, S, generator=g).to(cuda)
+    ref_bn = torch.nn.BatchNorm2d(C).to(cuda).double().train()
+    ref_bn.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    pr = F.relu(ref_bn(xr)).max(dim=3)[0]
+    pr.backward(dpool.double())
+    xh = x.clone().requires_grad_(True)
+    assert hb.supported_maxk(xh, bn)
+    ph = hb.batch_norm_train_relu_max(xh, bn)
+    ph.backward(dpool)
+
+    def close(a, r, what):
+        scale = r.abs().max().item()
+        err = (a.double() - r).abs().max().item()
+        assert err <= 1e-5 * scale + 1e-12, (what, err, scale)
+    close(ph, pr.detach(), "pooled")
+    close(bn.running_mean, ref_bn.running_mean, "running_mean")
+    close(bn.running_var, ref_bn.running_var, "running_var")
+    assert int(bn.num_batches_tracked) == 1
+    close(xh.grad, xr.grad, "dx")
+    close(bn.weight.grad, ref_bn.weight.grad, "dgamma")
+    close(bn.bias.grad, ref_bn.bias.grad, "dbeta")
+
+
+def test_shared_mlp_max_is_the_stack_followed_by_max(cuda):
+    """pytorch_utils.shared_mlp_max on a training-mode SharedMLP equals mlp(x).max(dim=3)[0] -- values, running
+    statistics and parameter gradients -- and falls back to exactly that in eval mode."""
+    import copy
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pytorch_utils as pt
+    torch.manual_seed(11)
+    mlp = pt.SharedMLP([19, 16, 16, 32], bn=True).to(cuda).train()
+    ref = copy.deepcopy(mlp)
+    x = torch.randn(2, 19, 128, 16, device=cuda)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    a = pt.shared_mlp_max(mlp, xa)
+    b = ref(xb).max(dim=3)[0]
+    assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+    w = torch.randn_like(a)
+    (a * w).sum().backward()
+    (b * w).sum().backward()
+    assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * xb.grad.abs().max().item()
+    for (n, p), (_, q) in zip(mlp.named_parameters(), ref.named_parameters()):
+        assert (p.grad - q.grad).abs().max().item() <= 1e-4 * q.grad.abs().max().item() + 1e-7, n
+    for (n, p), (_, q) in zip(mlp.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(p.float(), q.float(), rtol=1e-5, atol=1e-6), n
+    mlp.eval()
+    ref.eval()
+    with torch.no_grad():
+        assert torch.equal(pt.shared_mlp_max(mlp, x), ref(x).max(dim=3)[0])
