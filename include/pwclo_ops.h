@@ -210,6 +210,13 @@ void ingest_pairs_kernel_wrapper(int b, int n, const float *xyz_f1, const float 
 void ingest_frames_kernel_wrapper(int b, int n, int n_total, int c, const float *frame1,
                                   const float *frame2, float *out);
 
+/* Hamilton product of quaternion rows (PW/PWCLO_utils.py:83-95 mul_q_point, :117-129 mul_point_q -- the same
+ * component expressions): out (b,4,n) = a (b,4,na) (x) q (b,4,nb), na and nb each 1 (broadcast) or n; conj_a / conj_b
+ * != 0 use that operand's conjugate.  Products rounded before the left-to-right sums: the torch expression bit for
+ * bit.  The product's gradients are products with conjugates, so the training path's backward calls this again. */
+void hamilton_product_kernel_wrapper(int b, int n, int na, int nb, int conj_a, int conj_b, const float *a,
+                                     const float *q, float *out);
+
 /* quat_warp_kernel_wrapper on point-major clouds: xyz, out (b,n,3). */
 void quat_warp_pm_kernel_wrapper(int b, int n, const float *xyz, const float *q, const float *t,
                                  float *out);

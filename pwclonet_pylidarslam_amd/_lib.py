@@ -48,6 +48,7 @@ SIGNATURES = {
     "sa_fused_kernel_wrapper": ([_i] * 8 + [_F] * 6, None),
     "furthest_point_sampling_xyz_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F], None),
     "furthest_point_sampling_chain_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F, _F, _i, _F], None),
+    "hamilton_product_kernel_wrapper": ([_i] * 6 + [_F] * 3, None),
     "quat_warp_pm_kernel_wrapper": ([_i, _i, _F, _F, _F, _F], None),
     "ingest_pairs_kernel_wrapper": ([_i, _i, _F, _F, _F], None),
     "ingest_frames_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F], None),

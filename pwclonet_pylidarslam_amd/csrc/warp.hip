@@ -194,6 +194,42 @@ extern "C" void ingest_pairs_kernel_wrapper(int b, int n, const float *xyz_f1, c
   check_launch("ingest_pairs");
 }
 
+// Hamilton product of two batches of quaternion rows, c[b][:, n] = a[b][:, n or 0] (x) b[b][:, n or 0], rows (B, 4, N)
+// (PW/PWCLO_utils.py:83-95 mul_q_point and 117-129 mul_point_q: both are this product with the left operand's factors
+// first).  Every product is rounded before the sums, left to right as the reference's torch expression, so the result
+// is the expression's bit for bit.  conj_a / conj_b: use the conjugate (a0, -a1, -a2, -a3) of that operand -- the
+// product's gradients are products with conjugates (dA = dC (x) conj(B), dB = conj(A) (x) dC), so the same kernel
+// serves the backward.
+namespace pwclo {
+__global__ void hamilton_kernel(int n, int na, int nb, int conj_a, int conj_b, const float *__restrict__ a,
+                                const float *__restrict__ b, float *__restrict__ c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
+  if (i >= n) return;
+  const float *pa = a + (size_t)bi * 4 * na + (na == 1 ? 0 : i);
+  const float *pb = b + (size_t)bi * 4 * nb + (nb == 1 ? 0 : i);
+  const float sa = conj_a ? -1.f : 1.f, sb = conj_b ? -1.f : 1.f;
+  const float a0 = pa[0], a1 = sa * pa[na], a2 = sa * pa[2 * na], a3 = sa * pa[3 * na];
+  const float b0 = pb[0], b1 = sb * pb[nb], b2 = sb * pb[2 * nb], b3 = sb * pb[3 * nb];
+  float *pc = c + (size_t)bi * 4 * n + i;
+  auto m = [](float u, float v) { return __fmul_rn(u, v); };
+  pc[0] = __fsub_rn(__fsub_rn(__fsub_rn(m(a0, b0), m(a1, b1)), m(a2, b2)), m(a3, b3));
+  pc[n] = __fsub_rn(__fadd_rn(__fadd_rn(m(a0, b1), m(a1, b0)), m(a2, b3)), m(a3, b2));
+  pc[2 * n] = __fadd_rn(__fadd_rn(__fsub_rn(m(a0, b2), m(a1, b3)), m(a2, b0)), m(a3, b1));
+  pc[3 * n] = __fadd_rn(__fsub_rn(__fadd_rn(m(a0, b3), m(a1, b2)), m(a2, b1)), m(a3, b0));
+}
+}  // namespace pwclo
+
+extern "C" void hamilton_product_kernel_wrapper(int b, int n, int na, int nb, int conj_a, int conj_b, const float *a,
+                                                const float *q, float *out) {
+  if (b <= 0 || n <= 0) return;
+  PWCLO_REQUIRE(b <= 65535, "hamilton_product: b=%d exceeds the grid limit", b);
+  PWCLO_REQUIRE((na == 1 || na == n) && (nb == 1 || nb == n), "hamilton_product: operand lengths %d, %d must be 1 or n=%d",
+                na, nb, n);
+  hipLaunchKernelGGL(pwclo::hamilton_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, current_stream(), n, na, nb, conj_a,
+                     conj_b, a, q, out);
+  check_launch("hamilton_product");
+}
+
 extern "C" void quat_warp_kernel_wrapper(int b, int n, const float *xyz, const float *q,
                                          const float *t, float *out) {
   if (b <= 0 || n <= 0) return;

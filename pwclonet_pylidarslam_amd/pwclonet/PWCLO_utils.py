@@ -9,9 +9,52 @@ import torch
 from ..pointnet2_ops import _ext
 
 
+class _Hamilton(torch.autograd.Function):
+    """The Hamilton product on one kernel (csrc/warp.hip hamilton_kernel) instead of 16 products, 12 sums and a stack:
+    forward values are the torch expression's bit for bit; the gradients are products with conjugates
+    (dA = dC (x) conj(B), dB = conj(A) (x) dC, summed over N for a broadcast operand), computed by the same op -- so
+    it is differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, a, b, conj_a, conj_b):
+        a, b = a.contiguous(), b.contiguous()
+        B, n = a.shape[0], max(a.shape[2], b.shape[2])
+        out = torch.empty((B, 4, n), dtype=torch.float32, device=a.device)
+        from .. import _lib
+        _lib.call("hamilton_product_kernel_wrapper", a.device, B, n, a.shape[2], b.shape[2], int(conj_a), int(conj_b),
+                  a.data_ptr(), b.data_ptr(), out.data_ptr())
+        ctx.save_for_backward(a, b)
+        ctx.conj = (bool(conj_a), bool(conj_b))
+        return out
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        ca, cb = ctx.conj
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            # C = A' (x) B' with A' = A or conj(A): dA' = dC (x) conj(B'); dA = conj(dA') when A' = conj(A)
+            da = _Hamilton.apply(dc, b, False, not cb)
+            if ca:
+                da = torch.cat((da[:, :1], -da[:, 1:]), dim=1)
+            if a.shape[2] == 1 and da.shape[2] != 1:
+                da = da.sum(dim=2, keepdim=True)
+        if ctx.needs_input_grad[1]:
+            db = _Hamilton.apply(a, dc, not ca, False)
+            if cb:
+                db = torch.cat((db[:, :1], -db[:, 1:]), dim=1)
+            if b.shape[2] == 1 and db.shape[2] != 1:
+                db = db.sum(dim=2, keepdim=True)
+        return da, db, None, None
+
+
 def _hamilton(a, b):
     """(B,4,N) (x) (B,4,1|N): same component expressions for mul_q_point and mul_point_q
     (PWCLO_utils.py:83-95, 117-129 -- both list the left operand's factors first)."""
+    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 3 and b.dim() == 3 \
+            and a.shape[1] == 4 and b.shape[1] == 4 and a.shape[0] == b.shape[0] \
+            and (a.shape[2] == b.shape[2] or a.shape[2] == 1 or b.shape[2] == 1):
+        return _Hamilton.apply(a, b, False, False)
     a0, a1, a2, a3 = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
     b0, b1, b2, b3 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
     return torch.stack((a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3,

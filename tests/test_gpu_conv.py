@@ -208,3 +208,36 @@ def test_shared_mlp_max_is_the_stack_followed_by_max(cuda):
     ref.eval()
     with torch.no_grad():
         assert torch.equal(pt.shared_mlp_max(mlp, x), ref(x).max(dim=3)[0])
+
+
+@pytest.mark.parametrize("na,nb", [(1, 257), (257, 1), (64, 64), (1, 1)])
+def test_hamilton_product_op_is_the_reference_expression(cuda, na, nb):
+    """PWCLO_utils._hamilton on csrc/warp.hip hamilton_kernel: forward bit-identical to the reference's component
+    expressions (PW/PWCLO_utils.py:83-95), first- and second-order gradients equal to autograd's on the expression
+    (broadcast operands included)."""
+    from pwclonet_pylidarslam_amd.pwclonet import PWCLO_utils as U
+
+    def expr(a, b):
+        a0, a1, a2, a3 = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+        b0, b1, b2, b3 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+        return torch.stack((a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3, a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2,
+                            a0 * b2 - a1 * b3 + a2 * b0 + a3 * b1, a0 * b3 + a1 * b2 - a2 * b1 + a3 * b0), dim=1)
+    g = torch.Generator().manual_seed(na * 7 + nb)
+    a = torch.randn(3, 4, na, generator=g).to(cuda)
+    b = torch.randn(3, 4, nb, generator=g).to(cuda)
+    w = torch.randn(3, 4, max(na, nb), generator=g).to(cuda)
+    a1, b1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    c1, c2 = U._hamilton(a1, b1), expr(a2, b2)
+    assert torch.equal(c1, c2)
+    ga1, gb1 = torch.autograd.grad((c1 * w).sum(), (a1, b1), create_graph=True)
+    ga2, gb2 = torch.autograd.grad((c2 * w).sum(), (a2, b2), create_graph=True)
+    for u, v in ((ga1, ga2), (gb1, gb2)):
+        assert (u - v).abs().max().item() <= 1e-5 * v.abs().max().item()
+    # second order: d/da of sum(ga * gb-ish) exercises the conjugate flags
+    s1 = (ga1.square().sum() + gb1.square().sum())
+    s2 = (ga2.square().sum() + gb2.square().sum())
+    h1 = torch.autograd.grad(s1, (a1, b1))
+    h2 = torch.autograd.grad(s2, (a2, b2))
+    for u, v in zip(h1, h2):
+        assert (u - v).abs().max().item() <= 1e-4 * v.abs().max().item()
