@@ -190,10 +190,11 @@ def roofline_objects(fam):
     return roof, kernels
 
 
-def cpu_baseline(net, npoints, timed=5, threads=0):
+def cpu_baseline(net, npoints, timed=5, threads=0, seconds=12.0):
     """the CPU oracle (restatement of the reference path, pinned bit-identically to the
     imported reference in the build container) on the same KITTI-shaped pairs, batch 1 and batch 4, eval mode,
-    fp32, 1 warm-up + `timed` (>= 3) forwards each, MEDIAN reported.  All host cores are used: torch's CPU
+    fp32, 1 warm-up + at least `timed` (>= 3) forwards each and as many more as fit `seconds` / 2 of CPU work per
+    batch size (a bounded sample of 10-30 s in total), MEDIAN reported.  All host cores are used: torch's CPU
     convolutions with its default intra-op threads, the C ops' FPS (over clouds) and knn (over queries) loops
     with OpenMP.  `value` is the better of the two batch sizes.  A baseline, not a target."""
     from oracle import model as omodel, ops as oops
@@ -207,8 +208,8 @@ def cpu_baseline(net, npoints, timed=5, threads=0):
     rows, t_all = {}, time.perf_counter()
     for bsz in (1, 4):
         omodel.pwclonet_forward(sd, x1[:bsz], x2[:bsz])  # warm-up
-        ts = []
-        for _ in range(max(3, timed)):
+        ts, t_b = [], time.perf_counter()
+        while len(ts) < max(3, timed) or (time.perf_counter() - t_b < seconds / 2 and len(ts) < 400):
             t0 = time.perf_counter()
             omodel.pwclonet_forward(sd, x1[:bsz], x2[:bsz])
             ts.append(time.perf_counter() - t0)
@@ -219,10 +220,11 @@ def cpu_baseline(net, npoints, timed=5, threads=0):
     return {"value": best["pairs_per_s"], "unit": "frame-pairs/s", "cores": cores, "kind": "port",
             "os_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(),
             "c_ops_threads": oops.num_threads(), **rows,
-            "sample": "oracle.model on 2x%d-pt pairs: batch 1 and batch 4, 1 warm-up + %d timed forwards each, median; "
+            "sample": "oracle.model on 2x%d-pt pairs: batch 1 and batch 4, 1 warm-up + %d / %d timed forwards, median; "
                       "os.cpu_count() = %d, torch.get_num_threads() = %d, C ops (FPS over clouds, knn over queries) on "
                       "%d OpenMP threads; %.1f s of CPU work in total"
-                      % (npoints, max(3, timed), os.cpu_count(), torch.get_num_threads(), oops.num_threads(),
+                      % (npoints, rows["batch1"]["timed_forwards"], rows["batch4"]["timed_forwards"], os.cpu_count(),
+                         torch.get_num_threads(), oops.num_threads(),
                          time.perf_counter() - t_all)}
 
 
@@ -464,7 +466,8 @@ def main():
                     help="reference-shaped module graph on the HIP ops (torch conv/BN) instead of the fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-forwards", type=int, default=5, help="timed CPU forwards per batch size (>= 3)")
+    ap.add_argument("--cpu-forwards", type=int, default=5, help="timed CPU forwards per batch size (>= 3), at least")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample: seconds of CPU work in total")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="host threads of the CPU baseline (0 = the cgroup CPU quota / affinity of this process)")
     ap.add_argument("--no-variants", action="store_true",
@@ -597,7 +600,7 @@ def main():
             out["variants"] = {"bf16x3": bf16x3_variant(args, dev, x1, x2, ref_pose, pipe.streams, "bf16x3"),
                                "bf16": bf16x3_variant(args, dev, x1, x2, ref_pose, pipe.streams, "bf16")}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(net, args.npoints, args.cpu_forwards, args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(net, args.npoints, args.cpu_forwards, args.cpu_threads, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     dist_util.finish()
 

@@ -30,5 +30,11 @@ python tools/pmc_traffic.py "$(find $out/fetch -name '*counter_collection.csv' |
        "$(find $out/write -name '*counter_collection.csv' | head -1)" -o $out/pmc_traffic.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out/sq -o sq -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
 python tools/pmc_mfma.py "$(find $out/sq -name '*counter_collection.csv' | head -1)" -o $out/pmc_mfma_busy.json > $out/pmc_mfma_busy.txt
+# training step of configs[3]'s per-GPU share: eager and graphed throughput, per-layer convolution table,
+# rocprofv3 kernel summary
+python tools/train_step.py --batch 32 --steps 10 --warmup 3 --fused-adam > $out/${tag}_train_step_b32.jsonl 2> /dev/null
+python tools/train_step.py --batch 32 --steps 10 --warmup 3 --fused-adam --graph >> $out/${tag}_train_step_b32.jsonl 2> /dev/null
+python tools/conv_table.py > $out/${tag}_train_conv_table.txt 2>&1
+bash tools/profile_train.sh 32 > /dev/null 2>&1 && cp gpurun_out/prof_train/summary.txt $out/${tag}_train_step_b32_kernel_summary.txt
 tail -c 300 $out/${tag}_default_bench_under_rocprof.json; echo
 ls -la $out
