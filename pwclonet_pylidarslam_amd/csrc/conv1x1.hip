@@ -12,6 +12,8 @@
 //     kernel (deterministic, no atomics).
 // v_mfma_f32_16x16x4_f32 everywhere: products and sums are fp32 FMAs, so the results differ from any other fp32
 // convolution by summation order only.
+#include <mutex>
+
 #include "common.hpp"
 
 namespace pwclo {
@@ -337,11 +339,21 @@ static WgradPlan wgrad_plan(int b, int cin, int cout, int p) {
   return pl;
 }
 
+// Kernels that need more than the default 64 KiB of dynamic LDS are allowed their maximum once per process (the
+// attribute call costs tens of microseconds of host time: not something to pay per launch).
 template <typename K>
 static bool allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return true;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)bytes) == hipSuccess;
+  static std::mutex mu;
+  static const void *seen[64];
+  static int nseen = 0;
+  const void *fn = reinterpret_cast<const void *>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < nseen; ++i)
+    if (seen[i] == fn) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+  if (nseen < 64) seen[nseen++] = fn;
+  return true;
 }
 
 static bool conv_args_ok(const char *what, int b, int cin, int cout, int p, const void *p0, const void *p1,

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
 template <int W, typename Kern, typename Args>
 static void launch_h(Kern kern, bool &attr_set, int lds_bytes, long long ntiles, const Args &a) {
   if (lds_bytes > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  // once per kernel: the largest any configuration can ask for
     attr_set = true;
   }
   static const int rounds = fh_tuning("PWCLO_FL_ROUNDS", 2);

@@ -723,7 +723,7 @@ static int fl_tuning(const char *name, int dflt) {   // PWCLO_FL_<NAME> override
 template <int W, typename Kern, typename Args>
 static void launch_persistent(Kern kern, bool &attr_set, int lds_bytes, long long ntiles, const Args &a) {
   if (lds_bytes > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  // once per kernel: the largest any configuration can ask for
     attr_set = true;
   }
   // Workgroups beyond one resident set queue behind it; >1 "rounds" keeps the kernel balanced when
