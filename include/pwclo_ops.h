@@ -348,6 +348,11 @@ void batchnorm_train_relu_maxk_backward_kernel_wrapper(int b, int c, int s, int 
  *                   gradient of the layer whose weight is w, called with x = dY, cin = the layer's cout). */
 void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w, int transposed,
                                     float *y);
+/* The forward with the layer's eval-mode BatchNorm and ReLU in the epilogue (P2/pytorch_utils.py:114-167: conv -> bn ->
+ * ReLU blocks in eval mode): y = act(conv(x) * scale[o] + shift[o]), scale = gamma / sqrt(running_var + eps), shift =
+ * beta - running_mean * scale (both (cout) f32, computed by the caller), act = ReLU when relu != 0. */
+void conv1x1_affine_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
+                                           const float *scale, const float *shift, int relu, float *y);
 /* dw (cout, cin) = sum over b, q of dy[b][o][q] x[b][i][q], summed in a fixed order (deterministic).  workspace:
  * conv1x1_wgrad_workspace_bytes(b, cin, cout, p) bytes of device memory, 16-byte aligned. */
 long long conv1x1_wgrad_workspace_bytes(int b, int cin, int cout, int p);

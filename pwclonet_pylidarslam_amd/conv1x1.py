@@ -91,3 +91,37 @@ class _Conv1x1(Function):
 def conv1x1(x, weight):
     """``F.conv{1,2,3}d(x, weight)`` for a size-1 kernel: x (B, Cin, *), weight (Cout, Cin, 1[, 1[, 1]])."""
     return _Conv1x1.apply(x, weight)
+
+
+def _folded(bn):
+    """Per-channel (scale, shift) of an eval-mode BatchNorm, cached on the module until one of its tensors changes
+    (version counters) or moves: a handful of tiny kernels once, not per call."""
+    tensors = (bn.running_mean, bn.running_var, bn.weight, bn.bias)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors) + (bn.eps,)
+    cached = getattr(bn, "_pwclo_folded", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    with torch.no_grad():
+        scale = torch.rsqrt(bn.running_var.float() + bn.eps)
+        if bn.weight is not None:
+            scale = scale * bn.weight.float()
+        shift = -bn.running_mean.float() * scale
+        if bn.bias is not None:
+            shift = shift + bn.bias.float()
+        scale, shift = scale.contiguous(), shift.contiguous()
+    object.__setattr__(bn, "_pwclo_folded", (key, scale, shift))
+    return scale, shift
+
+
+def conv1x1_bn_eval(x, conv, bn, relu):
+    """Eval-mode ``act(bn(conv(x)))`` of a conv -> BatchNorm [-> ReLU] block as ONE kernel (no autograd): the running
+    statistics folded to a per-channel scale / shift in the convolution's epilogue.  Same values as the three modules up
+    to fp32 rounding of the folded affine map."""
+    x = _aligned(x)
+    w = _aligned(conv.weight.detach())
+    B, cin, cout, P = _shape(x, w)
+    scale, shift = _folded(bn)
+    y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    _lib.call("conv1x1_affine_forward_kernel_wrapper", x.device, B, cin, cout, P, x.data_ptr(), w.data_ptr(),
+              scale.data_ptr(), shift.data_ptr(), int(bool(relu)), y.data_ptr())
+    return y

@@ -33,7 +33,9 @@ template <int NBO>
 __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kernel(int B, int Cin, int Cout, int P, int nbi,
                                                               long long w_ld_o, long long w_ld_i,
                                                               const float *__restrict__ x,
-                                                              const float *__restrict__ w, float *__restrict__ y) {
+                                                              const float *__restrict__ w, float *__restrict__ y,
+                                                              const float *__restrict__ ep_scale,
+                                                              const float *__restrict__ ep_shift, int ep_relu) {
   extern __shared__ float4 conv_w[];         // [NBO][nbi][64 lanes] : the 4 k-steps of one (o, m) tile per lane
   const int ob0 = blockIdx.y * NBO;
   {
@@ -134,7 +136,16 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int co = 16 * (ob0 + o) + 4 * g + r;
-                if (co < Cout) *reinterpret_cast<float2 *>(yb + (long long)co * P) = make_float2(acc[o][0][r], acc[o][1][r]);
+                if (co < Cout) {
+                  float v0 = acc[o][0][r], v1 = acc[o][1][r];
+                  if (ep_scale != nullptr) {   // eval-mode BatchNorm folded to y * scale + shift, optional ReLU
+                    const float sc = ep_scale[co], sh = ep_shift[co];
+                    v0 = v0 * sc + sh;
+                    v1 = v1 * sc + sh;
+                    if (ep_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                  }
+                  *reinterpret_cast<float2 *>(yb + (long long)co * P) = make_float2(v0, v1);
+                }
               }
           }
 #pragma unroll
@@ -378,10 +389,11 @@ static bool conv_args_ok(const char *what, int b, int cin, int cout, int p, cons
 
 using namespace pwclo;
 
-extern "C" void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
-                                               int transposed, float *y) {
+static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, const float *w, int transposed, float *y,
+                           const float *scale, const float *shift, int relu) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0) return;
   if (!conv_args_ok("conv1x1_forward", b, cin, cout, p, x, y, x)) return;
+  PWCLO_REQUIRE((scale == nullptr) == (shift == nullptr), "conv1x1_forward: scale and shift must be given together%s", "");
   // transposed = 1: w is stored (cin, cout) row-major -- the input-gradient pass of a layer whose weight it is.
   const long long ld_o = transposed ? 1 : cin, ld_i = transposed ? cout : 1;
   const int nbi = ceil_div(cin, 16), nbo_all = ceil_div(cout, 16);
@@ -400,7 +412,8 @@ extern "C" void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, 
 #define PWCLO_CONV_LAUNCH(N)                                                                                     \
   case N:                                                                                                        \
     PWCLO_REQUIRE(allow_lds(conv1x1_kernel<N>, lds), "conv1x1_forward: cannot reserve %zu bytes of LDS", lds);    \
-    hipLaunchKernelGGL((conv1x1_kernel<N>), grid, block, lds, st, b, cin, cout, p, nbi, ld_o, ld_i, x, w, y);     \
+    hipLaunchKernelGGL((conv1x1_kernel<N>), grid, block, lds, st, b, cin, cout, p, nbi, ld_o, ld_i, x, w, y,      \
+                       scale, shift, relu);                                                                      \
     break
   switch (nbo) {
     PWCLO_CONV_LAUNCH(1);
@@ -415,6 +428,16 @@ extern "C" void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, 
   }
 #undef PWCLO_CONV_LAUNCH
   check_launch("conv1x1_forward");
+}
+
+extern "C" void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
+                                               int transposed, float *y) {
+  conv1x1_launch(b, cin, cout, p, x, w, transposed, y, nullptr, nullptr, 0);
+}
+
+extern "C" void conv1x1_affine_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
+                                                      const float *scale, const float *shift, int relu, float *y) {
+  conv1x1_launch(b, cin, cout, p, x, w, 0, y, scale, shift, relu);
 }
 
 extern "C" long long conv1x1_wgrad_workspace_bytes(int b, int cin, int cout, int p) {

@@ -13,9 +13,10 @@ from .. import batchnorm as _hip_bn
 from .. import conv1x1 as _hip_conv
 
 _USE_HIP_BN = os.environ.get("PWCLO_HIP_BN", "1") != "0"
-# pointwise convolutions on csrc/conv1x1.hip: "grad" (default) = whenever autograd records the layer (training and
-# gradient checks), "all" = every GPU call, "0" = torch's convolution everywhere
-_USE_HIP_CONV = os.environ.get("PWCLO_HIP_CONV", "grad")
+# pointwise convolutions on csrc/conv1x1.hip: "all" (default) = every GPU call (no-grad eval blocks run conv + folded
+# BatchNorm + ReLU as one kernel), "grad" = only when autograd records the layer (training and gradient checks),
+# "0" = torch's convolution everywhere
+_USE_HIP_CONV = os.environ.get("PWCLO_HIP_CONV", "all")
 
 
 def _conv(conv, x):
@@ -110,6 +111,13 @@ class _ConvBlock(nn.Sequential):
             if _hip_bn.supported(y, mods[1][0]):
                 return _hip_bn.batch_norm_train(y, mods[1][0], relu=True)
             return mods[2](mods[1](y))
+        if (_USE_HIP_CONV == "all" and x.is_cuda and len(mods) in (2, 3) and isinstance(mods[1], _BN)
+                and isinstance(mods[0], (nn.Conv1d, nn.Conv2d, nn.Conv3d)) and (len(mods) == 2 or type(mods[2]) is nn.ReLU)
+                and not mods[1][0].training and mods[1][0].track_running_stats and mods[1][0].running_mean is not None
+                and not (torch.is_grad_enabled() and (x.requires_grad or mods[0].weight.requires_grad))
+                and _hip_conv.supported(x, mods[0])):
+            # eval mode, nothing recorded: convolution, folded BatchNorm and ReLU in one kernel
+            return _hip_conv.conv1x1_bn_eval(x, mods[0], mods[1][0], relu=len(mods) == 3)
         for m in mods:
             x = _conv(m, x) if isinstance(m, (nn.Conv1d, nn.Conv2d, nn.Conv3d)) else m(x)
         return x

@@ -241,3 +241,37 @@ def test_hamilton_product_op_is_the_reference_expression(cuda, na, nb):
     h2 = torch.autograd.grad(s2, (a2, b2))
     for u, v in zip(h1, h2):
         assert (u - v).abs().max().item() <= 1e-4 * v.abs().max().item()
+
+
+def test_eval_block_conv_bn_relu_is_one_kernel_with_the_modules_values(cuda):
+    """Eval mode, nothing recorded: pytorch_utils.Conv2d(bn=True) runs convolution + folded BatchNorm + ReLU as one
+    kernel (conv1x1_affine_forward); values equal the three torch modules' within 1e-5 of the output scale, the folded
+    parameters follow an in-place edit of the running statistics, and a recorded call still takes the autograd route."""
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pytorch_utils as pt
+    torch.manual_seed(5)
+    blk = pt.Conv2d(67, 128, bn=True).to(cuda)
+    bn = blk.bn.bn
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    blk.eval()
+    x = torch.randn(3, 67, 100, 8, device=cuda)
+
+    def stock():
+        with torch.no_grad():
+            return torch.relu(bn(torch.nn.functional.conv2d(x, blk.conv.weight)))
+    with torch.no_grad():
+        y = blk(x)
+    ref = stock()
+    assert (y - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    with torch.no_grad():
+        bn.running_mean.add_(0.25)                           # in-place edit: the cached fold must follow
+        y2 = blk(x)
+    ref2 = stock()
+    assert (y2 - ref2).abs().max().item() <= 1e-5 * ref2.abs().max().item()
+    assert (ref2 - ref).abs().max().item() > 1e-3
+    xr = x.clone().requires_grad_(True)
+    yr = blk(xr)                                             # recorded: separate ops, differentiable
+    assert yr.requires_grad and (yr - ref2).abs().max().item() <= 1e-5 * ref2.abs().max().item()
