@@ -353,6 +353,11 @@ void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, const float
  * beta - running_mean * scale (both (cout) f32, computed by the caller), act = ReLU when relu != 0. */
 void conv1x1_affine_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
                                            const float *scale, const float *shift, int relu, float *y);
+/* The same followed by the stack's max over the k neighbours (P2/pointnet2_modules.py: SharedMLP then .max(dim=3) /
+ * max_pool2d(kernel=[1, nsample])): x (b, cin, s, k), pooled (b, cout, s) = max_k act(conv(x) * scale + shift); the
+ * (b, cout, s, k) activation is not written.  k in {4, 8, 16, 32}. */
+void conv1x1_affine_maxk_forward_kernel_wrapper(int b, int cin, int cout, int s, int k, const float *x, const float *w,
+                                                const float *scale, const float *shift, int relu, float *pooled);
 /* dw (cout, cin) = sum over b, q of dy[b][o][q] x[b][i][q], summed in a fixed order (deterministic).  workspace:
  * conv1x1_wgrad_workspace_bytes(b, cin, cout, p) bytes of device memory, 16-byte aligned. */
 long long conv1x1_wgrad_workspace_bytes(int b, int cin, int cout, int p);

@@ -125,3 +125,17 @@ def conv1x1_bn_eval(x, conv, bn, relu):
     _lib.call("conv1x1_affine_forward_kernel_wrapper", x.device, B, cin, cout, P, x.data_ptr(), w.data_ptr(),
               scale.data_ptr(), shift.data_ptr(), int(bool(relu)), y.data_ptr())
     return y
+
+
+def conv1x1_bn_eval_maxk(x, conv, bn, relu):
+    """``act(bn(conv(x))).max(dim=3)[0]`` for x (B, Cin, S, K), K in {4, 8, 16, 32}, eval mode, no autograd: one
+    kernel, the (B, Cout, S, K) activation is never written."""
+    x = _aligned(x)
+    w = _aligned(conv.weight.detach())
+    B, cin, S, K = x.shape
+    cout = w.shape[0]
+    scale, shift = _folded(bn)
+    pooled = torch.empty((B, cout, S), dtype=torch.float32, device=x.device)
+    _lib.call("conv1x1_affine_maxk_forward_kernel_wrapper", x.device, B, cin, cout, S, K, x.data_ptr(), w.data_ptr(),
+              scale.data_ptr(), shift.data_ptr(), int(bool(relu)), pooled.data_ptr())
+    return pooled

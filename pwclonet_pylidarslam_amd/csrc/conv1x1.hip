@@ -35,7 +35,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y,
                                                               const float *__restrict__ ep_scale,
-                                                              const float *__restrict__ ep_shift, int ep_relu) {
+                                                              const float *__restrict__ ep_shift, int ep_relu, int ep_pool) {
   extern __shared__ float4 conv_w[];         // [NBO][nbi][64 lanes] : the 4 k-steps of one (o, m) tile per lane
   const int ob0 = blockIdx.y * NBO;
   {
@@ -78,13 +78,14 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
   // The wave's work is one stream of (tile, 16-channel block) steps.  A load cursor runs CONV_AHEAD steps ahead of
   // the multiply cursor through a ring of register buffers, so a block has CONV_AHEAD multiply steps (of this wave
   // and of the waves sharing its SIMD) to arrive from HBM -- tile boundaries included.
-  struct Cursor { long long t; int m; const float *xb; long long yoff; bool pv; };
+  struct Cursor { long long t; int m; const float *xb; int b, px; bool pv; };
   auto locate = [&](Cursor &c) {
     const int b = (int)(c.t / tpb);
     const int px = ((int)(c.t - (long long)b * tpb) << 5) + 2 * j;
     c.pv = c.t < tiles && px < P;
     c.xb = x + (long long)b * Cin * P + px;
-    c.yoff = (long long)b * Cout * P + px;
+    c.b = b;
+    c.px = px;
   };
   auto advance = [&](Cursor &c) {
     if (++c.m == nbi) {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
       d[s] = (c.pv && ch < Cin) ? *reinterpret_cast<const float2 *>(c.xb + (long long)ch * P) : make_float2(0.f, 0.f);
     }
   };
-  Cursor lc{t0, 0, nullptr, 0, false}, mc{t0, 0, nullptr, 0, false};
+  Cursor lc{t0, 0, nullptr, 0, 0, false}, mc{t0, 0, nullptr, 0, 0, false};
   locate(lc);
   locate(mc);
 #pragma unroll
@@ -130,21 +131,30 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
         advance(lc);
         if (mc.m == nbi - 1) {
           if (mc.pv) {
-            float *yb = y + mc.yoff;
+            // ep_pool = K > 0: the row of K consecutive pixels (K / 2 neighbouring lanes, rows never straddle a 32-pixel
+            // tile) is reduced to its maximum and only that is written: y is (B, Cout, P / K)
+            float *yb = ep_pool > 0 ? y + ((long long)mc.b * Cout * (P / ep_pool) + mc.px / ep_pool)
+                                    : y + ((long long)mc.b * Cout * P + mc.px);
+            const long long cstride = ep_pool > 0 ? P / ep_pool : P;
+            const bool writer = ep_pool > 0 && (mc.px % ep_pool) == 0;
 #pragma unroll
             for (int o = 0; o < NBO; ++o)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int co = 16 * (ob0 + o) + 4 * g + r;
-                if (co < Cout) {
-                  float v0 = acc[o][0][r], v1 = acc[o][1][r];
-                  if (ep_scale != nullptr) {   // eval-mode BatchNorm folded to y * scale + shift, optional ReLU
-                    const float sc = ep_scale[co], sh = ep_shift[co];
-                    v0 = v0 * sc + sh;
-                    v1 = v1 * sc + sh;
-                    if (ep_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                  }
-                  *reinterpret_cast<float2 *>(yb + (long long)co * P) = make_float2(v0, v1);
+                float v0 = acc[o][0][r], v1 = acc[o][1][r];
+                if (ep_scale != nullptr && co < Cout) {   // eval-mode BatchNorm folded to y * scale + shift, optional ReLU
+                  const float sc = ep_scale[co], sh = ep_shift[co];
+                  v0 = v0 * sc + sh;
+                  v1 = v1 * sc + sh;
+                  if (ep_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                }
+                if (ep_pool > 0) {
+                  float mx = fmaxf(v0, v1);
+                  for (int off = 1; off < (ep_pool >> 1); off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                  if (writer && co < Cout) yb[(long long)co * cstride] = mx;
+                } else if (co < Cout) {
+                  *reinterpret_cast<float2 *>(yb + (long long)co * cstride) = make_float2(v0, v1);
                 }
               }
           }
@@ -390,10 +400,12 @@ static bool conv_args_ok(const char *what, int b, int cin, int cout, int p, cons
 using namespace pwclo;
 
 static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, const float *w, int transposed, float *y,
-                           const float *scale, const float *shift, int relu) {
+                           const float *scale, const float *shift, int relu, int pool = 0) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0) return;
   if (!conv_args_ok("conv1x1_forward", b, cin, cout, p, x, y, x)) return;
   PWCLO_REQUIRE((scale == nullptr) == (shift == nullptr), "conv1x1_forward: scale and shift must be given together%s", "");
+  PWCLO_REQUIRE(pool == 0 || ((pool == 4 || pool == 8 || pool == 16 || pool == 32) && p % pool == 0),
+                "conv1x1_forward: pooled rows of k=%d pixels need k in {4,8,16,32} dividing p=%d", pool, p);
   // transposed = 1: w is stored (cin, cout) row-major -- the input-gradient pass of a layer whose weight it is.
   const long long ld_o = transposed ? 1 : cin, ld_i = transposed ? cout : 1;
   const int nbi = ceil_div(cin, 16), nbo_all = ceil_div(cout, 16);
@@ -413,7 +425,7 @@ static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, cons
   case N:                                                                                                        \
     PWCLO_REQUIRE(allow_lds(conv1x1_kernel<N>, lds), "conv1x1_forward: cannot reserve %zu bytes of LDS", lds);    \
     hipLaunchKernelGGL((conv1x1_kernel<N>), grid, block, lds, st, b, cin, cout, p, nbi, ld_o, ld_i, x, w, y,      \
-                       scale, shift, relu);                                                                      \
+                       scale, shift, relu, pool);                                                                \
     break
   switch (nbo) {
     PWCLO_CONV_LAUNCH(1);
@@ -438,6 +450,12 @@ extern "C" void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, 
 extern "C" void conv1x1_affine_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
                                                       const float *scale, const float *shift, int relu, float *y) {
   conv1x1_launch(b, cin, cout, p, x, w, 0, y, scale, shift, relu);
+}
+
+extern "C" void conv1x1_affine_maxk_forward_kernel_wrapper(int b, int cin, int cout, int s, int k, const float *x,
+                                                           const float *w, const float *scale, const float *shift,
+                                                           int relu, float *pooled) {
+  conv1x1_launch(b, cin, cout, s * k, x, w, 0, pooled, scale, shift, relu, k);
 }
 
 extern "C" long long conv1x1_wgrad_workspace_bytes(int b, int cin, int cout, int p) {

@@ -138,6 +138,15 @@ def shared_mlp_max(mlp, x):
         if _hip_bn.supported_maxk(y, mods[1][0]):
             return _hip_bn.batch_norm_train_relu_max(y, mods[1][0])
         return mods[2](mods[1](y)).max(dim=3)[0]
+    if (_USE_HIP_CONV == "all" and x.is_cuda and len(mods) == 3 and isinstance(mods[0], nn.Conv2d)
+            and isinstance(mods[1], _BN) and type(mods[2]) is nn.ReLU and not mods[1][0].training
+            and mods[1][0].track_running_stats and mods[1][0].running_mean is not None and not torch.is_grad_enabled()):
+        # eval mode, nothing recorded: the last layer's convolution, folded BatchNorm, ReLU and the max in one kernel
+        for layer in layers[:-1]:
+            x = layer(x)
+        if x.dim() == 4 and x.shape[3] in (4, 8, 16, 32) and _hip_conv.supported(x, mods[0]):
+            return _hip_conv.conv1x1_bn_eval_maxk(x, mods[0], mods[1][0], relu=True)
+        return layers[-1](x).max(dim=3)[0]
     return mlp(x).max(dim=3)[0]
 
 

@@ -275,3 +275,34 @@ def test_eval_block_conv_bn_relu_is_one_kernel_with_the_modules_values(cuda):
     xr = x.clone().requires_grad_(True)
     yr = blk(xr)                                             # recorded: separate ops, differentiable
     assert yr.requires_grad and (yr - ref2).abs().max().item() <= 1e-5 * ref2.abs().max().item()
+
+
+@pytest.mark.parametrize("K,S", [(32, 100), (16, 36), (8, 257), (4, 64)])
+def test_eval_stack_tail_conv_bn_relu_max_in_one_kernel(cuda, K, S):
+    """pytorch_utils.shared_mlp_max in eval mode with nothing recorded: the last layer's convolution, folded BatchNorm,
+    ReLU and the max over K as one kernel (conv1x1_affine_maxk_forward) -- equal to the modules followed by
+    .max(dim=3)[0] within 1e-5 of the output scale; ragged S (tiles that end inside a batch element) included."""
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pytorch_utils as pt
+    torch.manual_seed(K + S)
+    mlp = pt.SharedMLP([35, 32, 32, 64], bn=True).to(cuda)
+    for m in mlp.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.running_mean.normal_()
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_()
+    mlp.eval()
+    x = torch.randn(3, 35, S, K, device=cuda)
+    old = pt._USE_HIP_CONV
+    try:
+        pt._USE_HIP_CONV = "0"
+        with torch.no_grad():
+            ref = mlp(x).max(dim=3)[0]
+        pt._USE_HIP_CONV = "all"
+        with torch.no_grad():
+            got = pt.shared_mlp_max(mlp, x)
+    finally:
+        pt._USE_HIP_CONV = old
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
