@@ -8,6 +8,7 @@ folded into the packed weights on the fused path).
 """
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 
@@ -37,6 +38,7 @@ class _BatchNormTrain(Function):
         return y
 
     @staticmethod
+    @once_differentiable            # raw kernels: a second differentiation raises instead of returning constants
     def backward(ctx, dy):
         x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         dy = dy.contiguous()
@@ -93,6 +95,7 @@ class _BatchNormReluMaxK(Function):
         return pooled
 
     @staticmethod
+    @once_differentiable            # raw kernels: a second differentiation raises instead of returning constants
     def backward(ctx, dpool):
         x, weight, bias, save_mean, save_invstd, arg, xsel = ctx.saved_tensors
         dpool = dpool.contiguous()

@@ -9,6 +9,7 @@ summation order; the weight gradient is summed in a fixed order (deterministic).
 """
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 
@@ -70,6 +71,7 @@ class _Conv1x1(Function):
         return _forward(x, w, False, cin, cout)
 
     @staticmethod
+    @once_differentiable            # raw kernels: a second differentiation raises instead of returning constants
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = _aligned(dy)
