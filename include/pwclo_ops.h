@@ -53,6 +53,14 @@ void pwclo_clear_error(void);
  * Synchronous (writes device symbols); not for use under graph capture. */
 void pwclo_trace_enable(void *records, void *count, unsigned capacity);
 
+/* How furthest_point_sampling launches its multi-workgroup kernel for clouds too large for one workgroup (n > 24576):
+ * cooperative != 0 (default; PWCLO_FPS_COOP_LAUNCH): hipLaunchCooperativeKernel -- co-residency guaranteed by the
+ * runtime, but the device has ONE cooperative queue: such launches on different streams run one after the other;
+ * cooperative == 0: plain launch, for a caller that keeps two large-cloud batches in flight and bounds the workgroups in
+ * flight itself (<= 256 of this kernel).  Either way a workgroup that waits for its peers beyond the spin bound reports
+ * PWCLO_ECOOP_TIMEOUT through pwclo_last_error(); the indices are never silently incomplete.  Process-wide. */
+void pwclo_fps_large_cloud_launch(int cooperative);
+
 #define PWCLO_EINVAL 10001  /* argument outside what the kernels support (message says which) */
 /* Reported by a RUNNING kernel (not at launch): the cooperative large-cloud sampler gave up waiting for a
  * peer workgroup.  Kernels post such codes into a pinned word the library owns; pwclo_last_error() reads it

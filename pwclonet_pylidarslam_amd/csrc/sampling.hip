@@ -21,6 +21,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "common.hpp"
 
 PWCLO_TRACE_TU(sampling)
@@ -869,7 +871,13 @@ extern "C" void group_points_grad_kernel_wrapper(int b, int c, int n, int npoint
 // hipLaunchCooperativeKernel makes the runtime guarantee exactly that (the launch is REJECTED if the grid cannot be
 // co-resident, and the grid is dispatched as a whole even when other streams hold CUs); a stream under graph capture
 // cannot take a cooperative launch, there the plain launch with the 224-workgroup cap is used and the bounded
-// spins + error word are the safety net.  PWCLO_FPS_COOP_LAUNCH=0 forces the plain launch.
+// spins + error word are the safety net.  The cooperative API runs on the device's one cooperative queue, so two such
+// launches on different streams SERIALISE; a caller that keeps two large-cloud batches in flight (each 128 of the 256
+// CUs: bench.py --config 5) selects the plain launch with pwclo_fps_large_cloud_launch(0) (or PWCLO_FPS_COOP_LAUNCH=0):
+// co-residency then holds by construction as long as at most 256 workgroups of this kernel are in flight and the other
+// kernels on the device are short -- and a violation still ends in PWCLO_ECOOP_TIMEOUT, never in wrong indices.
+static std::atomic<int> g_coop_api{-1};     // -1: not decided (PWCLO_FPS_COOP_LAUNCH, default 1); set by pwclo_fps_large_cloud_launch
+
 static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const float *dataset,
                         unsigned long long *ws, int *idxs, float *new_xyz, const int *perm,
                         const float *orig_dataset) {
@@ -881,8 +889,12 @@ static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const fl
   int spin_limit = holdback ? 256 : (1 << 21);
   hipLaunchKernelGGL(fps_coop_init_kernel, dim3(ceil_div(b * COOP_WS_WORDS, 256)), dim3(256), 0, st, ws,
                      b * COOP_WS_WORDS);
-  static int coop_api = -1;
-  if (coop_api < 0) { const char *e = getenv("PWCLO_FPS_COOP_LAUNCH"); coop_api = e ? atoi(e) : 1; }
+  int coop_api = g_coop_api.load();
+  if (coop_api < 0) {
+    const char *e = getenv("PWCLO_FPS_COOP_LAUNCH");
+    coop_api = e ? atoi(e) : 1;
+    g_coop_api.store(coop_api);
+  }
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
   const bool use_coop_api = coop_api && cap == hipStreamCaptureStatusNone;
@@ -1087,3 +1099,5 @@ extern "C" void gather_points_grad_kernel_wrapper(int b, int c, int n, int npoin
                      current_stream(), c, n, npoints, grad_out, idx, grad_points);
   check_launch("gather_points_grad");
 }
+
+extern "C" void pwclo_fps_large_cloud_launch(int cooperative) { g_coop_api.store(cooperative ? 1 : 0); }

@@ -139,6 +139,42 @@ def test_fps_cooperative_timeout_is_reported(cuda, monkeypatch):
         E.gather_points(g(torch.zeros(1, 3, 8), cuda), g(torch.zeros(1, 4, dtype=torch.int32), cuda))
 
 
+def test_fps_two_large_cloud_batches_in_flight_with_the_plain_launch(cuda):
+    """bench.py --config 5 keeps TWO batches in flight: the cooperative-launch API would run their samplers one after
+    the other (one cooperative queue per device), so that mode selects the plain launch
+    (pwclo_fps_large_cloud_launch(0)).  Two such samplers on two streams, 2 x 8 clouds x 8 workgroups side by side,
+    return exactly what one cooperative launch returns for each batch (which test_fps_large_cloud_cooperative pins to
+    the C oracle), and no time-out is reported.  Run once."""
+    from pwclonet_pylidarslam_amd import _lib
+    gen = torch.Generator().manual_seed(9)
+    xa = g((torch.rand(8, 60000, 3, generator=gen) * 2 - 1) * 40, cuda)
+    xb = g((torch.rand(8, 60000, 3, generator=gen) * 2 - 1) * 40, cuda)
+    ref_a = E.furthest_point_sampling(xa, 700)
+    ref_b = E.furthest_point_sampling(xb, 700)
+    torch.cuda.synchronize()
+    lib = _lib.load()
+    lib.pwclo_fps_large_cloud_launch(0)
+    try:
+        sa, sb = torch.cuda.Stream(device=cuda), torch.cuda.Stream(device=cuda)
+        main = torch.cuda.current_stream(cuda)
+        sa.wait_stream(main)
+        sb.wait_stream(main)
+        outs = []
+        for rep in range(2):
+            with torch.cuda.stream(sa):
+                oa = E.furthest_point_sampling(xa, 700)
+            with torch.cuda.stream(sb):
+                ob = E.furthest_point_sampling(xb, 700)
+            outs.append((oa, ob))
+        main.wait_stream(sa)
+        main.wait_stream(sb)
+        _lib.synchronize(cuda)                               # raises if a workgroup timed out waiting for its peers
+    finally:
+        lib.pwclo_fps_large_cloud_launch(1)
+    for oa, ob in outs:
+        assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
+
+
 # ---------------------------------------------------------------- gather / group (+ grads)
 @pytest.mark.parametrize("b,c,n,m", [(2, 3, 8192, 2048), (3, 3, 256, 64), (2, 7, 100, 33), (1, 64, 1024, 1),
                                      (2, 3, 50000, 4096), (30, 16, 512, 128)])
