@@ -907,7 +907,7 @@ static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const fl
     (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_attr = true;
   }
-  const int per_launch = 224 / G;
+  const int per_launch = (224 * (1024 / COOP_T)) / G;   // plain launch: workgroups that are certainly co-resident on an idle device
   for (int c0 = 0; c0 < b; c0 += per_launch) {
     const int nb = min(per_launch, b - c0);
     const float *d0 = dataset + (size_t)c0 * n * 3;
