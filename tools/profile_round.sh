@@ -11,6 +11,7 @@ trap 'find $out -name "*.db" -delete; find $out -name "*kernel_trace.csv" -delet
 export TMPDIR=/tmp
 python bench.py > $out/${tag}_default_bench.json
 python bench.py --config 5 > $out/${tag}_config5_bench.json
+python bench.py --config 5 --config5-inflight 1 --no-cpu-baseline > $out/${tag}_config5_one_in_flight_bench.json
 python bench.py --batch 1 --no-cpu-baseline --no-variants > $out/${tag}_config2_batch1_bench.json
 python tools/launch_table.py > $out/${tag}_launch_table.txt 2>&1
 python tools/wgtrace.py > $out/${tag}_wgtrace_inflight4.txt 2>&1
