@@ -4,12 +4,14 @@
 // SharedMLP, pytorch_utils.py:12-37).  The library convolutions need NHWC transposes around their GEMMs for these
 // shapes (6..192 input channels, 8..128 output channels, up to 2M pixels); these kernels read and write the
 // channel-major rows as they are:
-//   * every lane loads / stores 4 consecutive pixels of one channel row (16 bytes; 16 lanes cover 256 contiguous
-//     bytes), which are the B operands (forward) of 4 independent 16-pixel MFMA columns;
-//   * the weights sit in LDS in MFMA A-operand order, one ds_read_b128 feeds 16 MFMAs;
+//   * forward / input gradient: every lane loads / stores 2 consecutive pixels of one channel row (16 lanes cover one
+//     128-byte line), the B operands of 2 independent 16-pixel MFMA columns; a load cursor runs CONV_AHEAD channel
+//     blocks ahead of the multiply cursor, across tile boundaries;
+//   * the weights sit in LDS in MFMA A-operand order, one ds_read_b128 feeds 8 MFMAs;
+//   * an optional epilogue folds an eval-mode BatchNorm (+ReLU) and the stack's max over K into the forward;
 //   * the weight gradient stages (dY, X) pixel chunks through LDS once per workgroup and every wave accumulates its
-//     own 16x16 (co, ci) tiles over the chunk; partial sums per workgroup are reduced in a fixed order by a second
-//     kernel (deterministic, no atomics).
+//     own rectangle of 16x16 (co, ci) tiles over the chunk; partial sums per workgroup are reduced in a fixed order by
+//     a second kernel (deterministic, no atomics).
 // v_mfma_f32_16x16x4_f32 everywhere: products and sums are fp32 FMAs, so the results differ from any other fp32
 // convolution by summation order only.
 #include <mutex>
@@ -27,7 +29,8 @@ constexpr int CONV_AHEAD = 4;               // channel blocks in flight per wave
 constexpr int WGRAD_MAXV = 7;                // float4 per thread of one staged weight-gradient chunk
 
 // y[b][co][p] = sum_ci W(co, ci) x[b][ci][p], W(co, ci) = w[co * w_ld_o + ci * w_ld_i]  (strides: the same kernel
-// computes the input gradient with the transposed view).  P % 4 == 0, rows 16-byte aligned.
+// computes the input gradient with the transposed view).  P % 4 == 0, rows 16-byte aligned.  Epilogue (forward only):
+// ep_scale / ep_shift (per output channel, nullable) and ep_relu; ep_pool = K > 0 writes max over each row of K pixels.
 // grid (x = persistent tile workers, y = groups of NBO output blocks); dynamic LDS = NBO * nbi KiB.
 template <int NBO>
 __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kernel(int B, int Cin, int Cout, int P, int nbi,
