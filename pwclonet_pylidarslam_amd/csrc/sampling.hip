@@ -606,7 +606,7 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
                                                           unsigned long long *__restrict__ ws,
                                                           int *__restrict__ idxs,
                                                           float *__restrict__ new_xyz, int spin_limit,
-                                                          int holdback, unsigned *host_err,
+                                                          int holdback, int poll_delay, unsigned *host_err,
                                                           const int *__restrict__ perm,
                                                           const float *__restrict__ orig_dataset) {
   extern __shared__ __attribute__((aligned(16))) unsigned pri_lds[];   // SORTED: [I][COOP_T] priorities
@@ -735,6 +735,9 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
       const unsigned long long *qs = gws + ((size_t)(it & 1) * COOP_MAX_G + lane) * COOP_SLOT_WORDS;
       unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull, w3 = 0ull, w4 = 0ull;
       bool done = false;
+      // the peers' posts need a fabric hop to land: a first poll issued at once misses them and costs a second round
+      // trip; poll_delay x 64 cycles of sleep first (tuned: PWCLO_FPS_COOP_POLL_DELAY)
+      for (int d = 0; d < poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
       for (int spin = 0; spin < spin_limit; ++spin) {
         bool ready = true;
         if (lane < G) {
@@ -887,6 +890,8 @@ static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const fl
   const char *dbg = getenv("PWCLO_FPS_COOP_DEBUG_TIMEOUT");   // test hook of the failure path (read per call)
   int holdback = dbg ? atoi(dbg) : 0;
   int spin_limit = holdback ? 256 : (1 << 21);
+  static int poll_delay = -1;
+  if (poll_delay < 0) { const char *e = getenv("PWCLO_FPS_COOP_POLL_DELAY"); poll_delay = e ? atoi(e) : 20; }   // 20 x 64 cycles: swept 0..32 on configs[4] (tools/scratch/poll_delay.sh)
   hipLaunchKernelGGL(fps_coop_init_kernel, dim3(ceil_div(b * COOP_WS_WORDS, 256)), dim3(256), 0, st, ws,
                      b * COOP_WS_WORDS);
   int coop_api = g_coop_api.load();
@@ -918,7 +923,7 @@ static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const fl
     const float *o0 = sorted ? orig_dataset + (size_t)c0 * n * 3 : nullptr;
     if (use_coop_api) {
       int nv = n, mv = m, bsv = bs, lbv = log2bs, Gv = G;
-      void *args[] = {&nv, &mv, &bsv, &lbv, &Gv, &d0, &w0, &i0, &x0, &spin_limit, &holdback, &host_err, &p0, &o0};
+      void *args[] = {&nv, &mv, &bsv, &lbv, &Gv, &d0, &w0, &i0, &x0, &spin_limit, &holdback, &poll_delay, &host_err, &p0, &o0};
       hipError_t e = hipLaunchCooperativeKernel(kern, dim3(G, nb), dim3(COOP_T), args, (unsigned)lds, st);
       if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -928,10 +933,10 @@ static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const fl
       }
     } else if (sorted) {
       hipLaunchKernelGGL((fps_coop_kernel<16, true>), dim3(G, nb), dim3(COOP_T), lds, st, n, m, bs, log2bs, G, d0, w0,
-                         i0, x0, spin_limit, holdback, host_err, p0, o0);
+                         i0, x0, spin_limit, holdback, poll_delay, host_err, p0, o0);
     } else {
       hipLaunchKernelGGL((fps_coop_kernel<16, false>), dim3(G, nb), dim3(COOP_T), 0, st, n, m, bs, log2bs, G, d0, w0,
-                         i0, x0, spin_limit, holdback, host_err, p0, o0);
+                         i0, x0, spin_limit, holdback, poll_delay, host_err, p0, o0);
     }
   }
   check_launch("furthest_point_sampling(coop)");
