@@ -60,6 +60,12 @@ void pwclo_trace_enable(void *records, void *count, unsigned capacity);
  * flight itself (<= 256 of this kernel).  Either way a workgroup that waits for its peers beyond the spin bound reports
  * PWCLO_ECOOP_TIMEOUT through pwclo_last_error(); the indices are never silently incomplete.  Process-wide. */
 void pwclo_fps_large_cloud_launch(int cooperative);
+/* The same kernel's cross-workgroup exchange.  xcd_local != 0 (default; PWCLO_FPS_COOP_XCD_LOCAL): the workgroups of a
+ * cloud are drawn from blocks with equal index mod 8, which the dispatcher deals to one XCD; every launch CHECKS that
+ * (the workgroups exchange their XCC ids first) and only then posts with plain stores that stay in that XCD's L2, where
+ * the peers' L1-bypassing polls find them (2.3 instead of 2.6 us per sample).  If the ids differ, or with xcd_local == 0,
+ * the posts are agent-scope stores as before.  Same indices either way.  Process-wide. */
+void pwclo_fps_large_cloud_exchange(int xcd_local);
 
 #define PWCLO_EINVAL 10001  /* argument outside what the kernels support (message says which) */
 /* Reported by a RUNNING kernel (not at launch): the cooperative large-cloud sampler gave up waiting for a

@@ -26,6 +26,7 @@ SIGNATURES = {
     "pwclo_last_error_message": ([], ctypes.c_char_p),
     "pwclo_clear_error": ([], None),
     "pwclo_fps_large_cloud_launch": ([_i], None),
+    "pwclo_fps_large_cloud_exchange": ([_i], None),
     "pwclo_trace_enable": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint], None),
     "gather_points_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F], None),
     "gather_points_grad_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F], None),

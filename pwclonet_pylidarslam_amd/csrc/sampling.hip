@@ -582,9 +582,15 @@ __global__ void fps_coop_init_kernel(unsigned long long *ws, int nwords) {
   if (i < nwords) ws[i] = 0ull;
 }
 
-__device__ __forceinline__ void coop_post(unsigned long long *w, unsigned payload, unsigned tag) {
-  __hip_atomic_store(w, ((unsigned long long)payload << 32) | (unsigned long long)tag, __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+// `local` = every workgroup of the cloud sits on ONE XCD (verified at kernel start): a plain store stays in that XCD's L2,
+// where the peers' L1-bypassing polls find it (an agent-scope store writes through to the fabric and drops the line, so
+// the poll pays the memory round trip).  Never used when the workgroups' XCC ids differ: other XCDs would not see it.
+__device__ __forceinline__ void coop_post(unsigned long long *w, unsigned payload, unsigned tag, bool local = false) {
+  const unsigned long long v = ((unsigned long long)payload << 32) | (unsigned long long)tag;
+  if (local)
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(w), "v"(v) : "memory");
+  else
+    __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // `spin_limit` bounds every poll loop; on expiry the workgroup raises the workspace's error word (so its peers
@@ -601,7 +607,7 @@ __device__ __forceinline__ void coop_post(unsigned long long *w, unsigned payloa
 // (LDS table), so the output is the unsorted kernel's, bit for bit.  At n ~ 1e5 a sample touches a handful of the
 // ~100 cells: the update leaves the critical path of most SIMDs.
 template <int I, bool SORTED>
-__global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, int log2bs, int G,
+__global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, int log2bs, int G, int nclouds, int xcd_local,
                                                           const float *__restrict__ dataset,
                                                           unsigned long long *__restrict__ ws,
                                                           int *__restrict__ idxs,
@@ -613,7 +619,13 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
   __shared__ unsigned long long slots[3];
   __shared__ unsigned long long bcast;      // winning key, ~0 = timed out
   __shared__ float bxyz[3];                 // its coordinates
-  const int g = blockIdx.x, cloud = blockIdx.y;
+  // 1-D grid of 8 * G * ceil(clouds / 8) workgroups.  Blocks are dealt round-robin over the 8 XCDs (observed, not a
+  // contract), so blocks with equal blockIdx.x % 8 share one: the G workgroups of a cloud are taken from one residue
+  // class.  Whether that really put them on one XCD is CHECKED below (XCC ids exchanged once); only then the fast
+  // exchange is used.
+  const int rclass = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int cloud = rclass + 8 * (q / G), g = q % G;
+  if (cloud >= nclouds) return;
   if (holdback && g == G - 1) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int vtid = g * COOP_T + tid, ttotal = G * COOP_T;
@@ -674,6 +686,35 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
   __syncthreads();
 
   bool failed = false;
+  // Placement check: every workgroup posts its XCC id (slot set 0, tag 0xFFFFFFFF: no iteration uses it, and set 0 is
+  // first written at iteration 2, which no peer reaches before all have left this check); all equal -> `local`.
+  bool local = false;
+  if (xcd_local) {
+    __shared__ int same_xcd;
+    if (tid < 64) {
+      const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
+      if (lane == 0) coop_post(gws + (size_t)g * COOP_SLOT_WORDS, xcc, 0xFFFFFFFFu);
+      const unsigned long long *qs = gws + (size_t)lane * COOP_SLOT_WORDS;
+      unsigned long long w0 = 0ull;
+      bool done = false;
+      for (int spin = 0; spin < spin_limit; ++spin) {
+        bool ready = true;
+        if (lane < G) {
+          w0 = __hip_atomic_load(qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ready = (unsigned)w0 == 0xFFFFFFFFu;
+        }
+        if (__ballot(ready) == ~0ull) { done = true; break; }
+        if ((spin & 63) == 63 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const unsigned mine_x = (unsigned)(w0 >> 32);
+      const unsigned first_x = (unsigned)__builtin_amdgcn_readfirstlane((int)mine_x);
+      const bool all_same = __ballot(lane < G && mine_x != first_x) == 0ull;
+      if (lane == 0) same_xcd = (done && all_same) ? 1 : 0;   // a time-out here is caught by the first iteration's poll
+    }
+    __syncthreads();
+    local = same_xcd != 0;
+  }
   // SORTED: the lane's candidate and the wave's arg-max persist across iterations whose update is skipped
   int bestj = 0;
   unsigned mine = 0u, wmax = 0u, wpri = 0xFFFFFFFFu, mypri = 0xFFFFFFFFu;
@@ -720,16 +761,16 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
 #pragma unroll
       for (int j = 1; j < I; ++j)
         if (bestj == j) { px = x[j]; py = y[j]; pz = z[j]; }
-      coop_post(mys + 2, __float_as_uint(px), tag);
-      coop_post(mys + 3, __float_as_uint(py), tag);
-      coop_post(mys + 4, __float_as_uint(pz), tag);
-      coop_post(mys + 1, (unsigned)(lkey & 0xFFFFFFFFull), tag);
-      coop_post(mys + 0, (unsigned)(lkey >> 32), tag);
+      coop_post(mys + 2, __float_as_uint(px), tag, local);
+      coop_post(mys + 3, __float_as_uint(py), tag, local);
+      coop_post(mys + 4, __float_as_uint(pz), tag, local);
+      coop_post(mys + 1, (unsigned)(lkey & 0xFFFFFFFFull), tag, local);
+      coop_post(mys + 0, (unsigned)(lkey >> 32), tag, local);
     }
     if (tid == 0) {
       slots[(it + 2) % 3] = 0ull;
       if (lkey == 0ull)                                  // no candidate in this workgroup: value 0
-        for (int w = 0; w < COOP_SLOT_WORDS; ++w) coop_post(mys + w, 0u, tag);
+        for (int w = 0; w < COOP_SLOT_WORDS; ++w) coop_post(mys + w, 0u, tag, local);
     }
     if (tid < 64) {                                      // wave 0 polls: lane q reads workgroup q's slot
       const unsigned long long *qs = gws + ((size_t)(it & 1) * COOP_MAX_G + lane) * COOP_SLOT_WORDS;
@@ -879,6 +920,7 @@ extern "C" void group_points_grad_kernel_wrapper(int b, int c, int n, int npoint
 // CUs: bench.py --config 5) selects the plain launch with pwclo_fps_large_cloud_launch(0) (or PWCLO_FPS_COOP_LAUNCH=0):
 // co-residency then holds by construction as long as at most 256 workgroups of this kernel are in flight and the other
 // kernels on the device are short -- and a violation still ends in PWCLO_ECOOP_TIMEOUT, never in wrong indices.
+static std::atomic<int> g_xcd_local{-1};    // -1: not decided (PWCLO_FPS_COOP_XCD_LOCAL, default 1); set by pwclo_fps_large_cloud_exchange
 static std::atomic<int> g_coop_api{-1};     // -1: not decided (PWCLO_FPS_COOP_LAUNCH, default 1); set by pwclo_fps_large_cloud_launch
 
 static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const float *dataset,
@@ -890,8 +932,14 @@ static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const fl
   const char *dbg = getenv("PWCLO_FPS_COOP_DEBUG_TIMEOUT");   // test hook of the failure path (read per call)
   int holdback = dbg ? atoi(dbg) : 0;
   int spin_limit = holdback ? 256 : (1 << 21);
+  int xcd_local = g_xcd_local.load();
+  if (xcd_local < 0) {
+    const char *e = getenv("PWCLO_FPS_COOP_XCD_LOCAL");
+    xcd_local = e ? atoi(e) : 1;
+    g_xcd_local.store(xcd_local);
+  }
   static int poll_delay = -1;
-  if (poll_delay < 0) { const char *e = getenv("PWCLO_FPS_COOP_POLL_DELAY"); poll_delay = e ? atoi(e) : 20; }   // 20 x 64 cycles: swept 0..32 on configs[4] (tools/scratch/poll_delay.sh)
+  if (poll_delay < 0) { const char *e = getenv("PWCLO_FPS_COOP_POLL_DELAY"); poll_delay = e ? atoi(e) : 12; }   // 12 x 64 cycles: swept 0..32 on configs[4] (tools/scratch/poll_delay.sh)
   hipLaunchKernelGGL(fps_coop_init_kernel, dim3(ceil_div(b * COOP_WS_WORDS, 256)), dim3(256), 0, st, ws,
                      b * COOP_WS_WORDS);
   int coop_api = g_coop_api.load();
@@ -912,7 +960,8 @@ static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const fl
     (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_attr = true;
   }
-  const int per_launch = (224 * (1024 / COOP_T)) / G;   // plain launch: workgroups that are certainly co-resident on an idle device
+  int per_launch = (224 * (1024 / COOP_T)) / G;         // plain launch: workgroups that are certainly co-resident on an idle device
+  if (per_launch >= 8) per_launch &= ~7;                // whole groups of 8 clouds: the grid is padded to 8 * G * ceil(clouds / 8)
   for (int c0 = 0; c0 < b; c0 += per_launch) {
     const int nb = min(per_launch, b - c0);
     const float *d0 = dataset + (size_t)c0 * n * 3;
@@ -921,10 +970,11 @@ static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const fl
     float *x0 = new_xyz ? new_xyz + (size_t)c0 * m * 3 : nullptr;
     const int *p0 = sorted ? perm + (size_t)c0 * n : nullptr;
     const float *o0 = sorted ? orig_dataset + (size_t)c0 * n * 3 : nullptr;
+    const dim3 grid(8 * G * ceil_div(nb, 8));            // workgroups of a cloud share blockIdx.x % 8 (see the kernel)
     if (use_coop_api) {
-      int nv = n, mv = m, bsv = bs, lbv = log2bs, Gv = G;
-      void *args[] = {&nv, &mv, &bsv, &lbv, &Gv, &d0, &w0, &i0, &x0, &spin_limit, &holdback, &poll_delay, &host_err, &p0, &o0};
-      hipError_t e = hipLaunchCooperativeKernel(kern, dim3(G, nb), dim3(COOP_T), args, (unsigned)lds, st);
+      int nv = n, mv = m, bsv = bs, lbv = log2bs, Gv = G, nbv = nb, xlv = xcd_local;
+      void *args[] = {&nv, &mv, &bsv, &lbv, &Gv, &nbv, &xlv, &d0, &w0, &i0, &x0, &spin_limit, &holdback, &poll_delay, &host_err, &p0, &o0};
+      hipError_t e = hipLaunchCooperativeKernel(kern, grid, dim3(COOP_T), args, (unsigned)lds, st);
       if (e != hipSuccess) {
         (void)hipGetLastError();
         set_error((int)e, "furthest_point_sampling(coop): cooperative launch of %d x %d workgroups rejected: %s",
@@ -932,10 +982,10 @@ static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const fl
         return;
       }
     } else if (sorted) {
-      hipLaunchKernelGGL((fps_coop_kernel<16, true>), dim3(G, nb), dim3(COOP_T), lds, st, n, m, bs, log2bs, G, d0, w0,
+      hipLaunchKernelGGL((fps_coop_kernel<16, true>), grid, dim3(COOP_T), lds, st, n, m, bs, log2bs, G, nb, xcd_local, d0, w0,
                          i0, x0, spin_limit, holdback, poll_delay, host_err, p0, o0);
     } else {
-      hipLaunchKernelGGL((fps_coop_kernel<16, false>), dim3(G, nb), dim3(COOP_T), 0, st, n, m, bs, log2bs, G, d0, w0,
+      hipLaunchKernelGGL((fps_coop_kernel<16, false>), grid, dim3(COOP_T), 0, st, n, m, bs, log2bs, G, nb, xcd_local, d0, w0,
                          i0, x0, spin_limit, holdback, poll_delay, host_err, p0, o0);
     }
   }
@@ -1106,3 +1156,5 @@ extern "C" void gather_points_grad_kernel_wrapper(int b, int c, int n, int npoin
 }
 
 extern "C" void pwclo_fps_large_cloud_launch(int cooperative) { g_coop_api.store(cooperative ? 1 : 0); }
+
+extern "C" void pwclo_fps_large_cloud_exchange(int xcd_local) { g_xcd_local.store(xcd_local ? 1 : 0); }

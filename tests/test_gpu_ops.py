@@ -175,6 +175,25 @@ def test_fps_two_large_cloud_batches_in_flight_with_the_plain_launch(cuda):
         assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
 
 
+def test_fps_large_cloud_exchange_modes_agree(cuda):
+    """The large-cloud sampler posts through the XCD's L2 when a launch finds all workgroups of a cloud on one XCD
+    (checked inside every launch) and with agent-scope stores otherwise; pwclo_fps_large_cloud_exchange(0) forces the
+    second protocol.  Both return the same indices (the default mode is pinned to the C oracle by
+    test_fps_large_cloud_cooperative).  Run once."""
+    from pwclonet_pylidarslam_amd import _lib
+    gen = torch.Generator().manual_seed(21)
+    x = g((torch.rand(3, 70001, 3, generator=gen) * 2 - 1) * 40, cuda)
+    ref = E.furthest_point_sampling(x, 900)
+    lib = _lib.load()
+    lib.pwclo_fps_large_cloud_exchange(0)
+    try:
+        got = E.furthest_point_sampling(x, 900)
+        _lib.synchronize(cuda)
+    finally:
+        lib.pwclo_fps_large_cloud_exchange(1)
+    assert torch.equal(got, ref)
+
+
 # ---------------------------------------------------------------- gather / group (+ grads)
 @pytest.mark.parametrize("b,c,n,m", [(2, 3, 8192, 2048), (3, 3, 256, 64), (2, 7, 100, 33), (1, 64, 1024, 1),
                                      (2, 3, 50000, 4096), (30, 16, 512, 128)])
