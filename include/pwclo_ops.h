@@ -313,6 +313,8 @@ void kitti360_filter_kernel_wrapper(int n, float ground_z, float near, const flo
 void compact_frames_kernel_wrapper(int b, int n, int cap, const int *keep, const int *pos, const float *xyz,
                                    float *out, int *counts);
 
+/* ---- 3b. module-path layers: training-mode BatchNorm, stack tails, pointwise convolution ---- */
+
 /* Training-mode BatchNorm over x (b, c, l) f32 (l = product of the trailing dimensions), the statistics pass of
  * the module path's Conv -> BN -> ReLU stacks (P2/pytorch_utils.py:86-111 wraps torch.nn.BatchNorm{1,2}d; semantics
  * of torch.nn.functional.batch_norm(training=True)): y = (x - mean) * invstd * gamma + beta with the batch's
