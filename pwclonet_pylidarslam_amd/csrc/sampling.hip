@@ -626,7 +626,7 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
   const int rclass = blockIdx.x & 7, q = blockIdx.x >> 3;
   const int cloud = rclass + 8 * (q / G), g = q % G;
   if (cloud >= nclouds) return;
-  if (holdback && g == G - 1) return;
+  if (holdback == 1 && g == G - 1) return;            // 2, 3: timing probes (results meaningless), see coop_launch
   const int tid = threadIdx.x, lane = tid & 63;
   const int vtid = g * COOP_T + tid, ttotal = G * COOP_T;
   const float *pts = dataset + (size_t)cloud * n * 3;
@@ -643,7 +643,10 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
 #pragma unroll
   for (int i = 0; i < I; ++i) {
     // unsorted: residue classes of the reference's thread partition; sorted: I * 64 consecutive positions per wave
-    const int k = SORTED ? ((g * (COOP_T / 64) + (tid >> 6)) * I + i) * 64 + lane : vtid + ttotal * i;
+    // sorted: cell c (I * 64 consecutive positions of the spatial order) goes to workgroup c % G, wave c / G -- a new
+    // sample wakes a handful of NEIGHBOURING cells, which this spreads over all workgroups and SIMDs instead of
+    // piling them onto the 16 waves of one workgroup (the iteration waits for the slowest workgroup)
+    const int k = SORTED ? (((tid >> 6) * G + g) * I + i) * 64 + lane : vtid + ttotal * i;
     float px = 0.f, py = 0.f, pz = 0.f, t0 = -1.0f;
     unsigned pr = 0xFFFFFFFFu;
     if (k < n) {
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
           w0 = __hip_atomic_load(qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ready = (unsigned)w0 == 0xFFFFFFFFu;
         }
-        if (__ballot(ready) == ~0ull) { done = true; break; }
+        if (__ballot(ready) == ~0ull || holdback == 3) { done = true; break; }   // probe 3: one poll, never wait
         if ((spin & 63) == 63 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
         __builtin_amdgcn_s_sleep(1);
       }
@@ -728,6 +731,7 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
       const float bd = gx * gx + gy * gy + gz * gz;            // the update's own expression on the box gap
       active = __builtin_amdgcn_readfirstlane((int)((unsigned)__float_as_int(bd) + 1u < gmax)) != 0;
     }
+    if (holdback == 2) active = false;                  // probe: exchange + barriers only
     if (active) {
       int best = __float_as_int(-1.0f);
       bestj = 0;
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(COOP_T) void fps_coop_kernel(int n, int m, int bs, 
           ready = (unsigned)w0 == tag && (unsigned)w1 == tag && (unsigned)w2 == tag && (unsigned)w3 == tag &&
                   (unsigned)w4 == tag;
         }
-        if (__ballot(ready) == ~0ull) { done = true; break; }
+        if (__ballot(ready) == ~0ull || holdback == 3) { done = true; break; }   // probe 3: one poll, never wait
         if ((spin & 63) == 63 &&
             __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
         __builtin_amdgcn_s_sleep(1);
@@ -931,7 +935,7 @@ static void coop_launch(int b, int n, int m, int bs, int log2bs, int G, const fl
   if (host_err == nullptr) return;
   const char *dbg = getenv("PWCLO_FPS_COOP_DEBUG_TIMEOUT");   // test hook of the failure path (read per call)
   int holdback = dbg ? atoi(dbg) : 0;
-  int spin_limit = holdback ? 256 : (1 << 21);
+  int spin_limit = holdback == 1 ? 256 : (1 << 21);
   int xcd_local = g_xcd_local.load();
   if (xcd_local < 0) {
     const char *e = getenv("PWCLO_FPS_COOP_XCD_LOCAL");
