@@ -46,10 +46,18 @@ def supported(x, conv):
     P = x.numel() // (x.shape[0] * cin)
     if P % 4 != 0 or cin > 512 or cout > 512 or x.shape[0] * (-(-P // 64)) >= 2 ** 31:
         return False
-    tiles = (-(-cin // 16)) * (-(-cout // 16))
-    ph = 1 if tiles >= 5 else 2 if tiles >= 3 else 4 if tiles == 2 else 8
+    # weight gradient: double-buffered 32-pixel chunks of all cin + cout rows in LDS, 7 float4 of staging per thread
     return (_fits(cin, cout) and _fits(cout, cin) and 2 * (cin + cout) * 36 * 4 <= 150 * 1024
-            and -(-tiles // (8 // ph)) <= 12)
+            and (cin + cout) * 8 <= 7 * 512 and _wgrad_split(cin, cout))
+
+
+def _wgrad_split(cin, cout):
+    """csrc/conv1x1.hip wgrad_plan: the 8 waves split into wo x wm workers over the (cout/16, cin/16) tile grid, each
+    owning at most 4 x 4 tiles (fewer than 5 tiles: one tile per worker, pixels split instead)."""
+    nbo, nbi = -(-cout // 16), -(-cin // 16)
+    if nbo * nbi < 5:
+        return True
+    return any(-(-nbo // wo) <= 4 and -(-nbi // (8 // wo)) <= 4 for wo in (1, 2, 4, 8))
 
 
 def _forward(x, w2d, transposed, cin, cout):

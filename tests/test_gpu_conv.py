@@ -306,3 +306,32 @@ def test_eval_stack_tail_conv_bn_relu_max_in_one_kernel(cuda, K, S):
         pt._USE_HIP_CONV = old
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_conv1x1_supported_matches_what_the_launchers_accept(cuda):
+    """conv1x1.supported() (Python) restates the launchers' limits (LDS for the packed weights, tiles per wave of the
+    weight gradient): for random channel counts up to 400 every shape it accepts runs forward and both gradients without
+    a library error and matches float64; a shape it rejects is left to torch by the Conv blocks."""
+    from pwclonet_pylidarslam_amd import _lib
+    from pwclonet_pylidarslam_amd import conv1x1
+    g = torch.Generator().manual_seed(77)
+    accepted = 0
+    for _ in range(24):
+        cin = int(torch.randint(1, 401, (1,), generator=g))
+        cout = int(torch.randint(1, 401, (1,), generator=g))
+        conv = torch.nn.Conv2d(cin, cout, 1, bias=False).to(cuda)
+        x = torch.randn(2, cin, 16, 8, generator=g).to(cuda)
+        if not conv1x1.supported(x, conv):
+            continue
+        accepted += 1
+        _lib.synchronize(cuda)
+        dy = torch.randn(2, cout, 128, generator=g).to(cuda)
+        y, dx, dw = _run(x.flatten(2), conv.weight.detach().flatten(1), dy)
+        ry, rdx, rdw = _ref(x.flatten(2), conv.weight.detach().flatten(1), dy)
+        _check(y, ry, "y %d->%d" % (cin, cout))
+        _check(dx, rdx, "dx %d->%d" % (cin, cout))
+        _check(dw, rdw, "dw %d->%d" % (cin, cout))
+    _lib.synchronize(cuda)
+    assert accepted >= 6
+    big = torch.nn.Conv2d(600, 64, 1, bias=False).to(cuda)
+    assert not conv1x1.supported(torch.randn(1, 600, 4, 4, device=cuda), big)
