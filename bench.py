@@ -360,6 +360,17 @@ def run_config5(args):
         _lib.load().pwclo_fps_large_cloud_launch(0)
     side = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else None
 
+    def front():                                        # filter, compaction, exact sampling: the sampler's stream
+        clouds, counts = preprocess.frames_to_clouds(frames, npts, dataset="kitti360", near_threshold=near)
+        return clouds[:B].transpose(1, 2).contiguous(), clouds[B:].transpose(1, 2).contiguous(), counts
+
+    def back(x1, x2):                                   # the pyramid
+        with torch.no_grad():
+            pose, _ = net(x1, None, x2, None)
+        return pose
+
+    pyr = torch.cuda.Stream(device=dev) if depth > 1 and args.config5_split else None
+
     def run_steps(k):
         out = None
         if side is None:
@@ -367,12 +378,25 @@ def run_config5(args):
                 out = step()
             return out
         main = torch.cuda.current_stream(dev)
-        for s_ in side:
+        for s_ in side + ([pyr] if pyr is not None else []):
             s_.wait_stream(main)
         for i in range(k):
-            with torch.cuda.stream(side[i % depth]):
-                out = step()
-        for s_ in side:
+            if pyr is None:
+                with torch.cuda.stream(side[i % depth]):
+                    out = step()
+            else:
+                # sampler streams carry only front ends: the next sampler starts the moment this one ends, the pyramid
+                # of the finished batch runs on its own stream beside it
+                with torch.cuda.stream(side[i % depth]):
+                    x1, x2, counts = front()
+                    ready = torch.cuda.Event()
+                    ready.record()
+                with torch.cuda.stream(pyr):
+                    pyr.wait_event(ready)
+                    x1.record_stream(pyr)
+                    x2.record_stream(pyr)
+                    out = (back(x1, x2), counts)
+        for s_ in side + ([pyr] if pyr is not None else []):
             main.wait_stream(s_)
         return out
 
@@ -424,7 +448,7 @@ def run_config5(args):
                    "global_batch": world * B, "npoints": npts, "parallelism": "replicas x%d" % world,
                    "launch": "eager; large-cloud sampler: %s" % ("plain launch, two batches in flight on two streams"
                                                                   if depth > 1 else "cooperative launch, one batch in flight"),
-                   "batches_in_flight": depth},
+                   "batches_in_flight": depth, "pyramids_on_their_own_stream": bool(pyr is not None)},
         "stages_ms": {"kitti360_filter": t_filter, "compaction": t_compact, "fps_%d_to_%d" % (n_surv, npts): t_fps,
                       "pyramid_kernels_%s" % args.dtype: t_pyr},
         "roofline": {"kernel": "fps_coop_kernel<16>", "bound": "hbm",
@@ -487,6 +511,9 @@ def main():
                     help="graph = replay one captured hipGraph per step (default); eager = Python launches")
     ap.add_argument("--config5-inflight", type=int, default=2,
                     help="--config 5: batches in flight, 1 or 2 (each sampler launch occupies half of the CUs)")
+    ap.add_argument("--config5-split", type=int, default=1,
+                    help="--config 5 with two batches in flight: 1 = pyramids on a third stream (sampler streams run only "
+                         "front ends)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batches in flight (graph launch only), each on its own stream: one batch's FPS chain "
                          "overlaps the others' neighbour-search/MLP kernels; 1 = strictly serial steps")
@@ -518,7 +545,7 @@ def main():
     pwclonet_pylidarslam_amd.configure_hw_queues(8)
 
     if args.steps is None:
-        args.steps = 6 if args.config == 5 else 40
+        args.steps = 16 if args.config == 5 else 40
     if args.batch is None:
         args.batch = 8 if args.config == 5 else 32
     if args.gpus > 1 and not dist_util.launched_by_torchrun():
