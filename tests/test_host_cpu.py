@@ -373,3 +373,28 @@ def test_pointwise_conv_shapes_of_the_network_are_the_tested_ones():
         elif isinstance(m, torch.nn.Conv1d):
             assert m.bias is not None
     assert shapes == set(mod.NET_SHAPES)
+
+
+def test_conv_blocks_on_cpu_are_plain_torch():
+    """The HIP routes of pytorch_utils (conv1x1, BatchNorm, stack tails) are taken for GPU tensors only: on CPU tensors
+    a Conv2d block and shared_mlp_max give exactly what the torch modules give, in train and eval mode -- the package
+    never computes on the CPU itself, torch does."""
+    import copy
+    import torch
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pytorch_utils as pt
+    from pwclonet_pylidarslam_amd import conv1x1
+    torch.manual_seed(0)
+    mlp = pt.SharedMLP([19, 16, 32], bn=True)
+    ref = copy.deepcopy(mlp)
+    x = torch.randn(2, 19, 12, 8)
+    for mode in ("train", "eval"):
+        getattr(mlp, mode)()
+        getattr(ref, mode)()
+        want = x
+        for layer in ref:                                   # the reference's forward: conv -> bn -> relu per layer
+            for m in layer:
+                want = m(want)
+        assert torch.equal(pt.shared_mlp_max(mlp, x), want.max(dim=3)[0])
+    assert not conv1x1.supported(x, mlp[0].conv)            # CPU tensor: never routed to the kernels
+    assert conv1x1._wgrad_split(192, 128) and conv1x1._wgrad_split(6, 8)
+    assert not conv1x1._wgrad_split(160, 144)               # 9 x 10 tiles: no 8-worker split with <= 4 x 4 per wave
