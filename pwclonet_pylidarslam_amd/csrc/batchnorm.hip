@@ -104,18 +104,31 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(int C, int L, lo
   }
 }
 
-// One thread per channel: fold the partials.
-__global__ void bn_forward_finish_kernel(int C, int nsplit, long long M, float eps, float momentum,
-                                         const double *__restrict__ partial, float *__restrict__ running_mean,
-                                         float *__restrict__ running_var, float *__restrict__ save_mean,
-                                         float *__restrict__ save_invstd) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int s = 0; s < nsplit; ++s) {
+// One WAVE per channel folds the partials: lane q sums splits q, q + 64, ... in order, the 64 lane sums are combined
+// by a fixed butterfly -- a fixed summation order (deterministic), a sixth of the latency of one thread walking up to
+// 256 partials (these two kernels run once per BatchNorm call: ~190 times per training step).
+__device__ __forceinline__ void bn_fold(const double *__restrict__ partial, int ch, int nsplit, double &s0, double &s1) {
+  const int lane = threadIdx.x & 63;
+  s0 = 0.0; s1 = 0.0;
+  for (int s = lane; s < nsplit; s += 64) {
     s0 += partial[((size_t)ch * nsplit + s) * 2 + 0];
     s1 += partial[((size_t)ch * nsplit + s) * 2 + 1];
   }
+  s0 = bn_wave_sum(s0);
+  s1 = bn_wave_sum(s1);
+}
+
+__global__ __launch_bounds__(256) void bn_forward_finish_kernel(int C, int nsplit, long long M, float eps, float momentum,
+                                                                const double *__restrict__ partial,
+                                                                float *__restrict__ running_mean,
+                                                                float *__restrict__ running_var,
+                                                                float *__restrict__ save_mean,
+                                                                float *__restrict__ save_invstd) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);        // 4 waves = 4 channels per workgroup
+  if (ch >= C) return;
+  double s0, s1;
+  bn_fold(partial, ch, nsplit, s0, s1);
+  if ((threadIdx.x & 63) != 0) return;
   const double mean = s0 / (double)M;
   double var = s1 / (double)M - mean * mean;     // fp64: no visible cancellation for fp32 data
   if (var < 0.0) var = 0.0;
@@ -128,15 +141,13 @@ __global__ void bn_forward_finish_kernel(int C, int nsplit, long long M, float e
   }
 }
 
-__global__ void bn_backward_finish_kernel(int C, int nsplit, const double *__restrict__ partial,
-                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_backward_finish_kernel(int C, int nsplit, const double *__restrict__ partial,
+                                                                 float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int s = 0; s < nsplit; ++s) {
-    s0 += partial[((size_t)ch * nsplit + s) * 2 + 0];
-    s1 += partial[((size_t)ch * nsplit + s) * 2 + 1];
-  }
+  double s0, s1;
+  bn_fold(partial, ch, nsplit, s0, s1);
+  if ((threadIdx.x & 63) != 0) return;
   dbeta[ch] = (float)s0;
   dgamma[ch] = (float)s1;
 }
@@ -324,7 +335,7 @@ extern "C" void batchnorm_train_forward_kernel_wrapper(int b, int c, int l, cons
   const float *none = nullptr;
   hipLaunchKernelGGL((bn_partial_kernel<0, false>), dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x,
                      none, none, none, none, none, partial);
-  hipLaunchKernelGGL(bn_forward_finish_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, st, c, nsplit, M, eps, momentum,
+  hipLaunchKernelGGL(bn_forward_finish_kernel, dim3(ceil_div(c, 4)), dim3(256), 0, st, c, nsplit, M, eps, momentum,
                      partial, running_mean, running_var, save_mean, save_invstd);
   if (relu)
     bn_launch_apply<0, true>(vec, b, c, l, 0.f, x, none, gamma, beta, save_mean, save_invstd, none, none, y, st);
@@ -354,7 +365,7 @@ extern "C" void batchnorm_train_backward_kernel_wrapper(int b, int c, int l, con
   else
     hipLaunchKernelGGL((bn_partial_kernel<1, false>), dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x,
                        dy, save_mean, save_invstd, gamma, beta, partial);
-  hipLaunchKernelGGL(bn_backward_finish_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, st, c, nsplit, partial, dgamma,
+  hipLaunchKernelGGL(bn_backward_finish_kernel, dim3(ceil_div(c, 4)), dim3(256), 0, st, c, nsplit, partial, dgamma,
                      dbeta);
   const float inv_m = (float)(1.0 / (double)M);
   if (relu)
@@ -394,7 +405,7 @@ extern "C" void batchnorm_train_relu_maxk_forward_kernel_wrapper(int b, int c, i
   const float *none = nullptr;
   hipLaunchKernelGGL((bn_partial_kernel<0, false>), dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, l, M, per_split, x,
                      none, none, none, none, none, partial);
-  hipLaunchKernelGGL(bn_forward_finish_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, st, c, nsplit, M, eps, momentum,
+  hipLaunchKernelGGL(bn_forward_finish_kernel, dim3(ceil_div(c, 4)), dim3(256), 0, st, c, nsplit, M, eps, momentum,
                      partial, running_mean, running_var, save_mean, save_invstd);
   const dim3 grid(ceil_div(l / 4, BN_THREADS), c, b);
 #define PWCLO_CALL(KK)                                                                                              \
@@ -425,7 +436,7 @@ extern "C" void batchnorm_train_relu_maxk_backward_kernel_wrapper(int b, int c, 
   hipStream_t st = current_stream();
   hipLaunchKernelGGL((bn_partial_kernel<1, true>), dim3(nsplit, c), dim3(BN_THREADS), 0, st, c, s, Ms, per_split, xsel,
                      dpool, save_mean, save_invstd, gamma, beta, partial);
-  hipLaunchKernelGGL(bn_backward_finish_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, st, c, nsplit, partial, dgamma,
+  hipLaunchKernelGGL(bn_backward_finish_kernel, dim3(ceil_div(c, 4)), dim3(256), 0, st, c, nsplit, partial, dgamma,
                      dbeta);
   const float inv_m = (float)(1.0 / ((double)b * s * k));
   const dim3 grid(ceil_div(s * k / 4, BN_THREADS), c, b);
