@@ -320,7 +320,8 @@ void compact_frames_kernel_wrapper(int b, int n, int cap, const int *keep, const
  * of torch.nn.functional.batch_norm(training=True)): y = (x - mean) * invstd * gamma + beta with the batch's
  * mean / biased variance per channel, running_* updated in place with `momentum` and the unbiased variance
  * (both may be NULL), save_mean / save_invstd (c) kept for the backward.  gamma / beta may be NULL (1 / 0).
- * workspace: batchnorm_train_workspace_bytes(c) bytes of device memory, 8-byte aligned. */
+ * workspace: batchnorm_train_workspace_bytes(c) bytes of device memory, 8-byte aligned.  y == NULL: statistics only
+ * (running_*, save_*), no apply pass -- for conv1x1_bnrelu_forward below. */
 long long batchnorm_train_workspace_bytes(int c);
 /* relu != 0 fuses the stack's following ReLU: y = max(., 0), and the backward masks dy where that output was 0
  * (the mask is recomputed from x, nothing extra is saved). */
@@ -369,6 +370,18 @@ void conv1x1_forward_kernel_wrapper(int b, int cin, int cout, int p, const float
  * beta - running_mean * scale (both (cout) f32, computed by the caller), act = ReLU when relu != 0. */
 void conv1x1_affine_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
                                            const float *scale, const float *shift, int relu, float *y);
+/* Training mode, interior layers of a stack: the convolution applies the PREVIOUS layer's BatchNorm (batch statistics)
+ * and ReLU to its input while loading it, a = max(((x - mean) * invstd) * gamma + beta, 0) (the expression of
+ * batchnorm_train_forward, bit for bit), so the normalised activation is never written: x (b, cin, p) is the previous
+ * convolution's output, in_mean / in_invstd (cin) its statistics (batchnorm_train_forward with y == NULL computes them
+ * without the apply pass), in_gamma / in_beta (cin) may be NULL (1 / 0).  The weight-gradient twin multiplies dy with the
+ * same transformed input. */
+void conv1x1_bnrelu_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
+                                           const float *in_mean, const float *in_invstd, const float *in_gamma,
+                                           const float *in_beta, float *y);
+void conv1x1_bnrelu_wgrad_kernel_wrapper(int b, int cin, int cout, int p, const float *dy, const float *x,
+                                         const float *in_mean, const float *in_invstd, const float *in_gamma,
+                                         const float *in_beta, float *dw, void *workspace);
 /* The same followed by the stack's max over the k neighbours (P2/pointnet2_modules.py: SharedMLP then .max(dim=3) /
  * max_pool2d(kernel=[1, nsample])): x (b, cin, s, k), pooled (b, cout, s) = max_k act(conv(x) * scale + shift); the
  * (b, cout, s, k) activation is not written.  k in {4, 8, 16, 32}. */

@@ -67,6 +67,8 @@ SIGNATURES = {
     "conv1x1_forward_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _i, _F], None),
     "conv1x1_affine_forward_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F, _i, _F], None),
     "conv1x1_affine_maxk_forward_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, _F, _F, _F, _i, _F], None),
+    "conv1x1_bnrelu_forward_kernel_wrapper": ([_i, _i, _i, _i] + [_F] * 7, None),
+    "conv1x1_bnrelu_wgrad_kernel_wrapper": ([_i, _i, _i, _i] + [_F] * 8, None),
     "conv1x1_wgrad_workspace_bytes": ([_i, _i, _i, _i], ctypes.c_longlong),
     "conv1x1_wgrad_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
     "group_points_grad_sorted_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, _F, _F, _F], None),

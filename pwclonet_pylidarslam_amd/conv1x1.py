@@ -30,25 +30,32 @@ def _fits(cin, cout):
     return nbi * (-(-nbo // gy)) <= 150                      # KiB of LDS for the packed weights
 
 
-def supported(x, conv):
-    """True when ``conv(x)`` is a bias-free pointwise convolution these kernels cover (forward and both gradients)."""
-    if not (isinstance(conv, (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Conv3d)) and x.is_cuda
-            and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and conv.bias is None
-            and conv.groups == 1 and conv.padding_mode == "zeros"):
+def supported_layer(conv, batch, pixels, ndim):
+    """``supported`` for an input described by its batch size, pixels per (batch, channel) row and rank only -- for
+    callers that check a whole stack before running its first layer."""
+    if not (isinstance(conv, (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Conv3d)) and conv.weight.dtype == torch.float32
+            and conv.bias is None and conv.groups == 1 and conv.padding_mode == "zeros"):
         return False
     if any(k != 1 for k in conv.kernel_size) or any(s != 1 for s in conv.stride) or any(d != 1 for d in conv.dilation):
         return False
     if isinstance(conv.padding, str) or any(p != 0 for p in conv.padding):
         return False
-    if x.dim() != conv.weight.dim() or x.shape[1] != conv.in_channels or x.numel() == 0:
+    if ndim != conv.weight.dim() or batch <= 0 or pixels <= 0:
         return False
-    cin, cout = conv.in_channels, conv.out_channels
-    P = x.numel() // (x.shape[0] * cin)
-    if P % 4 != 0 or cin > 512 or cout > 512 or x.shape[0] * (-(-P // 64)) >= 2 ** 31:
+    cin, cout, P = conv.in_channels, conv.out_channels, pixels
+    if P % 4 != 0 or cin > 512 or cout > 512 or batch * (-(-P // 64)) >= 2 ** 31:
         return False
     # weight gradient: double-buffered 32-pixel chunks of all cin + cout rows in LDS, 7 float4 of staging per thread
     return (_fits(cin, cout) and _fits(cout, cin) and 2 * (cin + cout) * 36 * 4 <= 150 * 1024
             and (cin + cout) * 8 <= 7 * 512 and _wgrad_split(cin, cout))
+
+
+def supported(x, conv):
+    """True when ``conv(x)`` is a bias-free pointwise convolution these kernels cover (forward and both gradients)."""
+    if not (isinstance(conv, (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Conv3d)) and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() >= 3 and x.shape[1] == conv.in_channels and x.numel() > 0):
+        return False
+    return supported_layer(conv, x.shape[0], x.numel() // (x.shape[0] * conv.in_channels), x.dim())
 
 
 def _wgrad_split(cin, cout):
@@ -149,3 +156,69 @@ def conv1x1_bn_eval_maxk(x, conv, bn, relu):
     _lib.call("conv1x1_affine_maxk_forward_kernel_wrapper", x.device, B, cin, cout, S, K, x.data_ptr(), w.data_ptr(),
               scale.data_ptr(), shift.data_ptr(), int(bool(relu)), pooled.data_ptr())
     return pooled
+
+
+class _BNReluConv(Function):
+    """Interior layer of a training-mode stack as ONE autograd node: BatchNorm (batch statistics) + ReLU of the previous
+    convolution's output ``x`` fused into this layer's convolution -- statistics pass, then the convolution applies the
+    normalisation while loading (the normalised activation is never written).  Backward: weight gradient on the same
+    transformed input, input gradient of the convolution, then the BatchNorm + ReLU backward on ``x`` (its ReLU mask is
+    recomputed from ``x`` like in batchnorm._BatchNormTrain)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, weight):
+        from . import batchnorm as hb
+        x = _aligned(x)
+        w = _aligned(weight.detach())
+        B, cin, cout, P = _shape(x, w)
+        mean = torch.empty((cin,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty((cin,), dtype=torch.float32, device=x.device)
+        ws = hb._workspace(cin, x.device)
+        p = lambda t: t.data_ptr() if t is not None else 0
+        _lib.call("batchnorm_train_forward_kernel_wrapper", x.device, B, cin, P, p(x), p(gamma), p(beta), float(eps),
+                  float(momentum), p(running_mean), p(running_var), 0, p(mean), p(invstd), p(ws), 1)
+        y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        _lib.call("conv1x1_bnrelu_forward_kernel_wrapper", x.device, B, cin, cout, P, p(x), p(w), p(mean), p(invstd),
+                  p(gamma), p(beta), p(y))
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        from . import batchnorm as hb
+        x, gamma, beta, mean, invstd, weight = ctx.saved_tensors
+        dy = _aligned(dy)
+        w = _aligned(weight.detach())
+        B, cin, cout, P = _shape(x, w)
+        p = lambda t: t.data_ptr() if t is not None else 0
+        dw = None
+        if ctx.needs_input_grad[7]:
+            nbytes = _lib.load().conv1x1_wgrad_workspace_bytes(B, cin, cout, P)
+            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+            dw = torch.empty_like(w)
+            _lib.call("conv1x1_bnrelu_wgrad_kernel_wrapper", x.device, B, cin, cout, P, p(dy), p(x), p(mean), p(invstd),
+                      p(gamma), p(beta), p(dw), p(ws))
+            dw = dw.view_as(weight)
+        dx = dgamma = dbeta = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            da = _forward(dy, w, True, cout, cin)                     # gradient w.r.t. the normalised, rectified input
+            dx = torch.empty_like(x)
+            dgamma = torch.empty((cin,), dtype=torch.float32, device=x.device)
+            dbeta = torch.empty((cin,), dtype=torch.float32, device=x.device)
+            ws2 = hb._workspace(cin, x.device)
+            _lib.call("batchnorm_train_backward_kernel_wrapper", x.device, B, cin, P, p(x), p(da), p(gamma), p(beta),
+                      p(mean), p(invstd), p(dx), p(dgamma), p(dbeta), p(ws2), 1)
+            if gamma is None:
+                dgamma = dbeta = None
+        return dx, dgamma, dbeta, None, None, None, None, dw
+
+
+def bn_relu_conv(x, bn, conv):
+    """``conv(relu(bn(x)))`` for a training-mode ``torch.nn.BatchNorm*`` module ``bn`` (updates its running statistics and
+    ``num_batches_tracked`` like ``bn(x)``) and a bias-free pointwise ``conv`` that ``supported(x, conv)`` accepts."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BNReluConv.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, conv.weight)

@@ -327,6 +327,7 @@ extern "C" void batchnorm_train_forward_kernel_wrapper(int b, int c, int l, cons
   const bool vec = (l % 4 == 0);
   PWCLO_REQUIRE(!vec || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0),
                 "batchnorm_train_forward: x and y must be 16-byte aligned%s", "");
+  const bool stats_only = (y == nullptr);     // the next layer's convolution applies the normalisation on its loads
   const long long M = (long long)b * l;
   long long per_split;
   const int nsplit = bn_splits(c, M, &per_split);
@@ -337,7 +338,8 @@ extern "C" void batchnorm_train_forward_kernel_wrapper(int b, int c, int l, cons
                      none, none, none, none, none, partial);
   hipLaunchKernelGGL(bn_forward_finish_kernel, dim3(ceil_div(c, 4)), dim3(256), 0, st, c, nsplit, M, eps, momentum,
                      partial, running_mean, running_var, save_mean, save_invstd);
-  if (relu)
+  if (stats_only) {
+  } else if (relu)
     bn_launch_apply<0, true>(vec, b, c, l, 0.f, x, none, gamma, beta, save_mean, save_invstd, none, none, y, st);
   else
     bn_launch_apply<0, false>(vec, b, c, l, 0.f, x, none, gamma, beta, save_mean, save_invstd, none, none, y, st);

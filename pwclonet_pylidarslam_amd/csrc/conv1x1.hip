@@ -38,7 +38,11 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y,
                                                               const float *__restrict__ ep_scale,
-                                                              const float *__restrict__ ep_shift, int ep_relu, int ep_pool) {
+                                                              const float *__restrict__ ep_shift, int ep_relu, int ep_pool,
+                                                              const float *__restrict__ in_mean,
+                                                              const float *__restrict__ in_invstd,
+                                                              const float *__restrict__ in_gamma,
+                                                              const float *__restrict__ in_beta) {
   extern __shared__ float4 conv_w[];         // [NBO][nbi][64 lanes] : the 4 k-steps of one (o, m) tile per lane
   const int ob0 = blockIdx.y * NBO;
   {
@@ -69,8 +73,17 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
         }
       }
     }
+    // in_mean != nullptr: the input is the PREVIOUS layer's convolution output and its training-mode BatchNorm + ReLU
+    // is applied on the fly, a = max(((x - mean) * invstd) * gamma + beta, 0) -- the expression of bn_apply_kernel, so
+    // the normalised activation is never written; per input channel (mean, invstd, gamma, beta), zeros for padding
+    float4 *conv_in = conv_w + NBO * nbi * WAVE;
+    if (in_mean != nullptr)
+      for (int c = threadIdx.x; c < nbi * 16; c += CONV_THREADS)
+        conv_in[c] = c < Cin ? make_float4(in_mean[c], in_invstd[c], in_gamma ? in_gamma[c] : 1.f, in_beta ? in_beta[c] : 0.f)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
   }
+  const float4 *conv_in = conv_w + NBO * nbi * WAVE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
   const int tpb = (P + 31) >> 5;             // 32-pixel tiles per batch element: lane (g, j) owns pixels 2j, 2j + 1
@@ -120,6 +133,14 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
 #pragma unroll
     for (int u = 0; u < CONV_AHEAD; ++u) {
       if (mc.t < tiles) {                    // wave-uniform
+        if (in_mean != nullptr) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float4 t = conv_in[16 * mc.m + 4 * s + g];
+            ring[u][s].x = fmaxf(((ring[u][s].x - t.x) * t.y) * t.z + t.w, 0.f);
+            ring[u][s].y = fmaxf(((ring[u][s].y - t.x) * t.y) * t.z + t.w, 0.f);
+          }
+        }
 #pragma unroll
         for (int o = 0; o < NBO; ++o) {
           const float4 a = conv_w[(o * nbi + mc.m) * WAVE + lane];
@@ -176,10 +197,11 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
 // workers (ph * wo * wm = 8); worker (a, c) owns the RO x RM rectangle of 16x16 tiles {(a + wo * r, c + wm * q)}
 // -- RO + RM operand reads feed RO * RM * 4 MFMAs per 16 pixels -- over the 16-pixel sub-chunks phase, phase + ph,
 // ...; the phases are summed in LDS and the workgroup writes partial row blockIdx.x.
-template <int RO, int RM>
-__global__ __launch_bounds__(CONV_THREADS, (RO * RM <= 2 ? 4 : 2)) void conv1x1_wgrad_kernel(
+template <int RO, int RM, bool XF>     // XF: X = max(bn(x), 0) applied while staging (in_mean ... in_beta)
+__global__ __launch_bounds__(CONV_THREADS, ((RO * RM <= 2 && !XF) ? 4 : 2)) void conv1x1_wgrad_kernel(
     int B, int Cin, int Cout, int P, int CP, int ph, int wo, int wm, const float *__restrict__ dy,
-    const float *__restrict__ x, float *__restrict__ partial) {
+    const float *__restrict__ x, float *__restrict__ partial, const float *__restrict__ in_mean,
+    const float *__restrict__ in_invstd, const float *__restrict__ in_gamma, const float *__restrict__ in_beta) {
   extern __shared__ float conv_s[];          // [2][(Cout + Cin) rows][CP + 4]
   const int rows = Cout + Cin, ld = CP + 4;
   const int nbo = (Cout + 15) >> 4, nbi = (Cin + 15) >> 4;
@@ -219,6 +241,14 @@ __global__ __launch_bounds__(CONV_THREADS, (RO * RM <= 2 ? 4 : 2)) void conv1x1_
         if (px < P) {
           const float *src = (r < Cout) ? dy + ((long long)b * Cout + r) * P : x + ((long long)b * Cin + (r - Cout)) * P;
           v = *reinterpret_cast<const float4 *>(src + px);
+          if (XF && r >= Cout) {                   // X = max(bn(x), 0) of the previous layer, as in the forward
+            const int ci = r - Cout;
+            const float mu = in_mean[ci], is = in_invstd[ci], ga = in_gamma ? in_gamma[ci] : 1.f, be = in_beta ? in_beta[ci] : 0.f;
+            v.x = fmaxf(((v.x - mu) * is) * ga + be, 0.f);
+            v.y = fmaxf(((v.y - mu) * is) * ga + be, 0.f);
+            v.z = fmaxf(((v.z - mu) * is) * ga + be, 0.f);
+            v.w = fmaxf(((v.w - mu) * is) * ga + be, 0.f);
+          }
         }
       }
       pre[u] = v;
@@ -403,7 +433,9 @@ static bool conv_args_ok(const char *what, int b, int cin, int cout, int p, cons
 using namespace pwclo;
 
 static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, const float *w, int transposed, float *y,
-                           const float *scale, const float *shift, int relu, int pool = 0) {
+                           const float *scale, const float *shift, int relu, int pool = 0,
+                           const float *in_mean = nullptr, const float *in_invstd = nullptr,
+                           const float *in_gamma = nullptr, const float *in_beta = nullptr) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0) return;
   if (!conv_args_ok("conv1x1_forward", b, cin, cout, p, x, y, x)) return;
   PWCLO_REQUIRE((scale == nullptr) == (shift == nullptr), "conv1x1_forward: scale and shift must be given together%s", "");
@@ -414,8 +446,9 @@ static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, cons
   const int nbi = ceil_div(cin, 16), nbo_all = ceil_div(cout, 16);
   const int gy = ceil_div(nbo_all, CONV_MAX_NBO);                       // groups of output blocks (input re-read per group)
   const int nbo = ceil_div(nbo_all, gy);
-  const size_t lds = (size_t)nbo * nbi * WAVE * sizeof(float4);
-  PWCLO_REQUIRE(lds <= 150 * 1024, "conv1x1_forward: cin=%d cout=%d need %zu bytes of LDS for the weights", cin, cout, lds);
+  const size_t lds = (size_t)nbo * nbi * WAVE * sizeof(float4) + (size_t)nbi * 16 * sizeof(float4);   // weights + input transform
+  PWCLO_REQUIRE((in_mean == nullptr) == (in_invstd == nullptr), "conv1x1_forward: in_mean and in_invstd must be given together%s", "");
+  PWCLO_REQUIRE(lds <= 154 * 1024, "conv1x1_forward: cin=%d cout=%d need %zu bytes of LDS for the weights", cin, cout, lds);
   const long long tiles = (long long)b * ceil_div(p, 32);
   const int per_cu = (lds <= 72 * 1024 && nbo <= 3) ? 2 : 1;             // workgroups a CU can hold (LDS, registers)
   long long gx = (long long)conv_grid_x() * per_cu / gy;
@@ -428,7 +461,7 @@ static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, cons
   case N:                                                                                                        \
     PWCLO_REQUIRE(allow_lds(conv1x1_kernel<N>, lds), "conv1x1_forward: cannot reserve %zu bytes of LDS", lds);    \
     hipLaunchKernelGGL((conv1x1_kernel<N>), grid, block, lds, st, b, cin, cout, p, nbi, ld_o, ld_i, x, w, y,      \
-                       scale, shift, relu, pool);                                                                \
+                       scale, shift, relu, pool, in_mean, in_invstd, in_gamma, in_beta);                         \
     break
   switch (nbo) {
     PWCLO_CONV_LAUNCH(1);
@@ -455,6 +488,12 @@ extern "C" void conv1x1_affine_forward_kernel_wrapper(int b, int cin, int cout, 
   conv1x1_launch(b, cin, cout, p, x, w, 0, y, scale, shift, relu);
 }
 
+extern "C" void conv1x1_bnrelu_forward_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
+                                                      const float *in_mean, const float *in_invstd,
+                                                      const float *in_gamma, const float *in_beta, float *y) {
+  conv1x1_launch(b, cin, cout, p, x, w, 0, y, nullptr, nullptr, 0, 0, in_mean, in_invstd, in_gamma, in_beta);
+}
+
 extern "C" void conv1x1_affine_maxk_forward_kernel_wrapper(int b, int cin, int cout, int s, int k, const float *x,
                                                            const float *w, const float *scale, const float *shift,
                                                            int relu, float *pooled) {
@@ -467,8 +506,9 @@ extern "C" long long conv1x1_wgrad_workspace_bytes(int b, int cin, int cout, int
   return (long long)pl.grid * cin * cout * (long long)sizeof(float);
 }
 
-extern "C" void conv1x1_wgrad_kernel_wrapper(int b, int cin, int cout, int p, const float *dy, const float *x,
-                                             float *dw, void *workspace) {
+static void conv1x1_wgrad_launch(int b, int cin, int cout, int p, const float *dy, const float *x, float *dw,
+                                 void *workspace, const float *in_mean, const float *in_invstd,
+                                 const float *in_gamma, const float *in_beta) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0) return;
   if (!conv_args_ok("conv1x1_wgrad", b, cin, cout, p, dy, x, workspace)) return;
   const WgradPlan pl = wgrad_plan(b, cin, cout, p);
@@ -478,18 +518,36 @@ extern "C" void conv1x1_wgrad_kernel_wrapper(int b, int cin, int cout, int p, co
   hipStream_t st = current_stream();
   float *partial = reinterpret_cast<float *>(workspace);
   PWCLO_REQUIRE(pl.ro > 0, "conv1x1_wgrad: cin=%d cout=%d: more than 4 x 4 tiles of 16 x 16 per wave", cin, cout);
+#define PWCLO_WGRAD_LAUNCH_X(R, M, X)                                                                                  \
+  {                                                                                                                    \
+    PWCLO_REQUIRE(allow_lds(conv1x1_wgrad_kernel<R, M, X>, pl.lds), "conv1x1_wgrad: cannot reserve %zu bytes of LDS",  \
+                  pl.lds);                                                                                             \
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<R, M, X>), dim3(pl.grid), dim3(CONV_THREADS), pl.lds, st, b, cin, cout, p, \
+                       pl.cp, pl.ph, pl.wo, pl.wm, dy, x, partial, in_mean, in_invstd, in_gamma, in_beta);             \
+  }
 #define PWCLO_WGRAD_LAUNCH(R, M)                                                                                       \
   if (pl.ro == R && pl.rm == M) {                                                                                      \
-    PWCLO_REQUIRE(allow_lds(conv1x1_wgrad_kernel<R, M>, pl.lds), "conv1x1_wgrad: cannot reserve %zu bytes of LDS",     \
-                  pl.lds);                                                                                             \
-    hipLaunchKernelGGL((conv1x1_wgrad_kernel<R, M>), dim3(pl.grid), dim3(CONV_THREADS), pl.lds, st, b, cin, cout, p,   \
-                       pl.cp, pl.ph, pl.wo, pl.wm, dy, x, partial);                                                    \
+    if (in_mean != nullptr) PWCLO_WGRAD_LAUNCH_X(R, M, true) else PWCLO_WGRAD_LAUNCH_X(R, M, false)                    \
   }
   PWCLO_WGRAD_LAUNCH(1, 1) PWCLO_WGRAD_LAUNCH(1, 2) PWCLO_WGRAD_LAUNCH(1, 3) PWCLO_WGRAD_LAUNCH(1, 4)
   PWCLO_WGRAD_LAUNCH(2, 1) PWCLO_WGRAD_LAUNCH(2, 2) PWCLO_WGRAD_LAUNCH(2, 3) PWCLO_WGRAD_LAUNCH(2, 4)
   PWCLO_WGRAD_LAUNCH(4, 1) PWCLO_WGRAD_LAUNCH(4, 2) PWCLO_WGRAD_LAUNCH(4, 3) PWCLO_WGRAD_LAUNCH(4, 4)
+#undef PWCLO_WGRAD_LAUNCH_X
 #undef PWCLO_WGRAD_LAUNCH
   const int n = cin * cout;
   hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(ceil_div(n, 32)), dim3(512), 0, st, n, pl.grid, partial, dw);
   check_launch("conv1x1_wgrad");
+}
+
+extern "C" void conv1x1_wgrad_kernel_wrapper(int b, int cin, int cout, int p, const float *dy, const float *x,
+                                             float *dw, void *workspace) {
+  conv1x1_wgrad_launch(b, cin, cout, p, dy, x, dw, workspace, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" void conv1x1_bnrelu_wgrad_kernel_wrapper(int b, int cin, int cout, int p, const float *dy, const float *x,
+                                                    const float *in_mean, const float *in_invstd,
+                                                    const float *in_gamma, const float *in_beta, float *dw,
+                                                    void *workspace) {
+  PWCLO_REQUIRE(in_mean != nullptr && in_invstd != nullptr, "conv1x1_bnrelu_wgrad: in_mean and in_invstd are required%s", "");
+  conv1x1_wgrad_launch(b, cin, cout, p, dy, x, dw, workspace, in_mean, in_invstd, in_gamma, in_beta);
 }

@@ -123,6 +123,38 @@ class _ConvBlock(nn.Sequential):
         return x
 
 
+# training-mode stacks: interior BatchNorm + ReLU folded into the next layer's convolution (conv1x1._BNReluConv), the last
+# layer's into the stack tail; "0" keeps one BatchNorm pass per layer
+_USE_HIP_STACK = os.environ.get("PWCLO_HIP_STACK", "1") != "0"
+
+
+def _train_stack(mlp, x, pooled):
+    """The whole SharedMLP in training mode with NO normalised activation written: layer 0's convolution, then for every
+    following layer ``conv_l(relu(bn_{l-1}(.)))`` as one node, then the last BatchNorm + ReLU (+ max over K when
+    ``pooled``).  None when the stack is not of that shape (the caller then runs it layer by layer)."""
+    layers = list(mlp)
+    if not (_USE_HIP_STACK and _USE_HIP_BN and _USE_HIP_CONV != "0" and x.is_cuda and x.dtype == torch.float32
+            and x.dim() == 4 and len(layers) >= 1):
+        return None
+    blocks = []
+    B, P = x.shape[0], x.shape[2] * x.shape[3]
+    for layer in layers:
+        mods = list(layer) if isinstance(layer, _ConvBlock) else []
+        if not (len(mods) == 3 and isinstance(mods[0], nn.Conv2d) and isinstance(mods[1], _BN) and type(mods[2]) is nn.ReLU
+                and mods[1][0].training and mods[1][0].momentum is not None
+                and (mods[1][0].weight is None) == (mods[1][0].bias is None)
+                and _hip_conv.supported_layer(mods[0], B, P, 4)):
+            return None
+        blocks.append((mods[0], mods[1][0]))
+    if blocks[0][0].in_channels != x.shape[1] or (pooled and x.shape[3] not in (4, 8, 16, 32)):
+        return None
+    y = _hip_conv.conv1x1(x, blocks[0][0].weight)
+    for (_, bn_prev), (conv, _) in zip(blocks[:-1], blocks[1:]):
+        y = _hip_conv.bn_relu_conv(y, bn_prev, conv)
+    last_bn = blocks[-1][1]
+    return _hip_bn.batch_norm_train_relu_max(y, last_bn) if pooled else _hip_bn.batch_norm_train(y, last_bn, relu=True)
+
+
 def shared_mlp_max(mlp, x):
     """``mlp(x).max(dim=3)[0]`` for a SharedMLP ``mlp`` on x (B, C, S, K) -- the tail every grouped stack of the
     reference ends with (P2/pointnet2_modules.py: SA, set-upconv).  In training mode on the GPU the last layer's
@@ -130,6 +162,10 @@ def shared_mlp_max(mlp, x):
     activation of the stack and its gradient are never written."""
     layers = list(mlp)
     mods = list(layers[-1]) if layers and isinstance(layers[-1], _ConvBlock) else []
+    if mods and isinstance(mods[1] if len(mods) > 1 else None, _BN) and mods[1][0].training:
+        out = _train_stack(mlp, x, pooled=True)
+        if out is not None:
+            return out
     if (_USE_HIP_BN and x.is_cuda and len(mods) == 3 and isinstance(mods[0], nn.Conv2d) and isinstance(mods[1], _BN)
             and type(mods[2]) is nn.ReLU and mods[1][0].training):
         for layer in layers[:-1]:
@@ -202,6 +238,13 @@ class FC(nn.Sequential):
 
 class SharedMLP(nn.Sequential):
     """pytorch_utils.py:52-83: ``layer{i}`` = Conv2d(1x1) [+ BN] + ReLU over (B,C,S,K)."""
+
+    def forward(self, x):
+        if self.training and x.is_cuda:
+            out = _train_stack(self, x, pooled=False)
+            if out is not None:
+                return out
+        return super().forward(x)
 
     def __init__(self, args: List[int], *, bn: bool = False, activation=nn.ReLU(inplace=True),
                  preact: bool = False, first: bool = False, name: str = "",

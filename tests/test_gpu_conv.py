@@ -194,7 +194,12 @@ def test_shared_mlp_max_is_the_stack_followed_by_max(cuda):
     x = torch.randn(2, 19, 128, 16, device=cuda)
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
     a = pt.shared_mlp_max(mlp, xa)
-    b = ref(xb).max(dim=3)[0]
+    saved = (pt._USE_HIP_STACK, pt._USE_HIP_CONV, pt._USE_HIP_BN)
+    pt._USE_HIP_STACK, pt._USE_HIP_CONV, pt._USE_HIP_BN = False, "0", False     # the reference side: torch's own ops
+    try:
+        b = ref(xb).max(dim=3)[0]
+    finally:
+        pt._USE_HIP_STACK, pt._USE_HIP_CONV, pt._USE_HIP_BN = saved
     assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
     w = torch.randn_like(a)
     (a * w).sum().backward()
@@ -207,7 +212,7 @@ def test_shared_mlp_max_is_the_stack_followed_by_max(cuda):
     mlp.eval()
     ref.eval()
     with torch.no_grad():
-        assert torch.equal(pt.shared_mlp_max(mlp, x), ref(x).max(dim=3)[0])
+        assert torch.equal(pt.shared_mlp_max(mlp, x), mlp(x).max(dim=3)[0])
 
 
 @pytest.mark.parametrize("na,nb", [(1, 257), (257, 1), (64, 64), (1, 1)])
@@ -335,3 +340,46 @@ def test_conv1x1_supported_matches_what_the_launchers_accept(cuda):
     assert accepted >= 6
     big = torch.nn.Conv2d(600, 64, 1, bias=False).to(cuda)
     assert not conv1x1.supported(torch.randn(1, 600, 4, 4, device=cuda), big)
+
+
+@pytest.mark.parametrize("pooled,K", [(True, 16), (False, 8), (True, 32), (False, 4)])
+def test_training_stack_without_normalised_activations_matches_torch(cuda, pooled, K):
+    """pytorch_utils._train_stack: a SharedMLP in training mode as conv -> [BN+ReLU fused into the next conv] ... ->
+    BN+ReLU(+max) with no normalised activation written, against the same stack evaluated by torch's own conv2d /
+    batch_norm / relu / max in float64: output, running statistics, input gradient and every parameter gradient.
+    Bounds: 1e-5 of the scale for values, 1e-4 for gradients (three BatchNorm backward passes in fp32)."""
+    import copy
+    import torch.nn.functional as F
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pytorch_utils as pt
+    torch.manual_seed(3 + K)
+    mlp = pt.SharedMLP([35, 32, 48, 64], bn=True).to(cuda).train()
+    for m in mlp.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0.0, 0.3)
+    ref = copy.deepcopy(mlp).double()
+    x = torch.randn(3, 35, 40, K, device=cuda)
+    xa = x.clone().requires_grad_(True)
+    out = pt._train_stack(mlp, xa, pooled)
+    assert out is not None
+    xr = x.double().requires_grad_(True)
+    h = xr
+    for layer in ref:
+        h = F.conv2d(h, layer.conv.weight)
+        bn = layer.bn.bn
+        h = F.relu(F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps))
+    want = h.max(dim=3)[0] if pooled else h
+    assert out.shape == want.shape
+    assert (out.double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    (want * w.double()).sum().backward()
+    assert (xa.grad.double() - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item()
+    for (n, p), (_, q) in zip(mlp.named_parameters(), ref.named_parameters()):
+        assert (p.grad.double() - q.grad).abs().max().item() <= 1e-4 * q.grad.abs().max().item() + 1e-9, n
+    for (n, p), (_, q) in zip(mlp.named_buffers(), ref.named_buffers()):
+        if p.is_floating_point():
+            assert (p.double() - q).abs().max().item() <= 1e-5 * max(q.abs().max().item(), 1.0), n
+        else:
+            assert int(p) == 1, n                             # num_batches_tracked (the float64 copy was not advanced)
