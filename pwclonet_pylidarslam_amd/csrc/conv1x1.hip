@@ -241,27 +241,36 @@ __global__ __launch_bounds__(CONV_THREADS, ((RO * RM <= 2 && !XF) ? 4 : 2)) void
         if (px < P) {
           const float *src = (r < Cout) ? dy + ((long long)b * Cout + r) * P : x + ((long long)b * Cin + (r - Cout)) * P;
           v = *reinterpret_cast<const float4 *>(src + px);
-          if (XF && r >= Cout) {                   // X = max(bn(x), 0) of the previous layer, as in the forward
-            const int ci = r - Cout;
-            const float mu = in_mean[ci], is = in_invstd[ci], ga = in_gamma ? in_gamma[ci] : 1.f, be = in_beta ? in_beta[ci] : 0.f;
-            v.x = fmaxf(((v.x - mu) * is) * ga + be, 0.f);
-            v.y = fmaxf(((v.y - mu) * is) * ga + be, 0.f);
-            v.z = fmaxf(((v.z - mu) * is) * ga + be, 0.f);
-            v.w = fmaxf(((v.w - mu) * is) * ga + be, 0.f);
-          }
         }
       }
       pre[u] = v;
     }
   };
-  auto put = [&](int buf) {
+  // XF: per-input-channel (mean, invstd, gamma, beta) of the previous layer's BatchNorm, in LDS behind the two stages;
+  // X = max(bn(x), 0) is applied when a fetched chunk is written to its stage (pixels beyond the row stay 0)
+  float4 *xf = reinterpret_cast<float4 *>(conv_s + (size_t)2 * rows * ld);
+  if (XF) {
+    for (int ci = threadIdx.x; ci < Cin; ci += CONV_THREADS)
+      xf[ci] = make_float4(in_mean[ci], in_invstd[ci], in_gamma ? in_gamma[ci] : 1.f, in_beta ? in_beta[ci] : 0.f);
+    __syncthreads();
+  }
+  auto put = [&](int buf, long long c) {
     float *dst = conv_s + (size_t)buf * rows * ld;
+    const int px0 = (int)(c - (c / cpb) * cpb) * CP;
 #pragma unroll
     for (int u = 0; u < WGRAD_MAXV; ++u) {
       const int e = threadIdx.x + u * CONV_THREADS;
       if (e < rows * vec) {
         const int r = e / vec, q = e - r * vec;
-        *reinterpret_cast<float4 *>(dst + (size_t)r * ld + 4 * q) = pre[u];
+        float4 v = pre[u];
+        if (XF && r >= Cout && px0 + 4 * q < P) {
+          const float4 t = xf[r - Cout];
+          v.x = fmaxf(((v.x - t.x) * t.y) * t.z + t.w, 0.f);
+          v.y = fmaxf(((v.y - t.x) * t.y) * t.z + t.w, 0.f);
+          v.z = fmaxf(((v.z - t.x) * t.y) * t.z + t.w, 0.f);
+          v.w = fmaxf(((v.w - t.x) * t.y) * t.z + t.w, 0.f);
+        }
+        *reinterpret_cast<float4 *>(dst + (size_t)r * ld + 4 * q) = v;
       }
     }
   };
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(CONV_THREADS, ((RO * RM <= 2 && !XF) ? 4 : 2)) void
   int buf = 0;
   if (c < chunks) {
     fetch(c);
-    put(0);
+    put(0, c);
   }
   __syncthreads();
   for (; c < chunks; c += gridDim.x) {
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(CONV_THREADS, ((RO * RM <= 2 && !XF) ? 4 : 2)) void
           acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].w, bv[q].w, acc[r][q], 0, 0, 0);
         }
     }
-    if (cn < chunks) put(buf ^ 1);          // the other buffer was last read before the previous barrier
+    if (cn < chunks) put(buf ^ 1, cn);      // the other buffer was last read before the previous barrier
     __syncthreads();
     buf ^= 1;
   }
@@ -518,11 +527,12 @@ static void conv1x1_wgrad_launch(int b, int cin, int cout, int p, const float *d
   hipStream_t st = current_stream();
   float *partial = reinterpret_cast<float *>(workspace);
   PWCLO_REQUIRE(pl.ro > 0, "conv1x1_wgrad: cin=%d cout=%d: more than 4 x 4 tiles of 16 x 16 per wave", cin, cout);
+  const size_t xf_lds = in_mean != nullptr ? (size_t)cin * sizeof(float4) : 0;   // the input transform's parameters
 #define PWCLO_WGRAD_LAUNCH_X(R, M, X)                                                                                  \
   {                                                                                                                    \
-    PWCLO_REQUIRE(allow_lds(conv1x1_wgrad_kernel<R, M, X>, pl.lds), "conv1x1_wgrad: cannot reserve %zu bytes of LDS",  \
+    PWCLO_REQUIRE(allow_lds(conv1x1_wgrad_kernel<R, M, X>, pl.lds + xf_lds), "conv1x1_wgrad: cannot reserve %zu bytes of LDS",  \
                   pl.lds);                                                                                             \
-    hipLaunchKernelGGL((conv1x1_wgrad_kernel<R, M, X>), dim3(pl.grid), dim3(CONV_THREADS), pl.lds, st, b, cin, cout, p, \
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<R, M, X>), dim3(pl.grid), dim3(CONV_THREADS), pl.lds + xf_lds, st, b, cin, cout, p, \
                        pl.cp, pl.ph, pl.wo, pl.wm, dy, x, partial, in_mean, in_invstd, in_gamma, in_beta);             \
   }
 #define PWCLO_WGRAD_LAUNCH(R, M)                                                                                       \
