@@ -2,9 +2,12 @@
 
 Functional style: every layer is a function of ``(state_dict, key_prefix, tensors)`` so the
 oracle shares nothing with the product's ``nn.Module`` mirror except the reference's
-``state_dict`` key names (SURVEY.md section 5 "checkpoint / resume").  Eval-mode semantics only
-(BatchNorm running statistics, dropout off): that is the mode the parity fixtures and the
-headline benchmark use (SURVEY.md section 7 "Hard parts").
+``state_dict`` key names (SURVEY.md section 5 "checkpoint / resume").  Eval-mode semantics
+(BatchNorm running statistics, dropout off) for ``pwclonet_forward``: the mode of the forward parity
+fixtures and the headline benchmark (SURVEY.md section 7 "Hard parts").  ``pwclonet_train_step`` is the
+TRAINING forward + loss + backward (batch-statistic BatchNorm with its running-statistics update, dropout
+off, autograd through the C ops' ``*_grad`` functions), pinned by tests/golden/train_n1024_b2.npz
+(oracle/gen_train_golden.py: values recorded from the imported reference in the same mode).
 
 Extension ops and ``knn_point`` come from ``oracle.ops`` (C restatement).  Citations:
 PW = /root/reference/slam/models/PWCLONet, P2 = .../pointnet2_ops_lib/pointnet2_ops.
@@ -19,6 +22,52 @@ import torch.nn.functional as F
 from oracle import ops
 
 BN_EPS = 1e-5  # nn.BatchNorm2d default, P2/pytorch_utils.py:95-103
+BN_MOMENTUM = 0.1  # nn.BatchNorm2d default (the reference passes no momentum, P2/pytorch_utils.py:95-103)
+_BN_TRAIN = False  # set by pwclonet_train_step for the duration of one call
+
+
+class _Group(torch.autograd.Function):
+    """P2/pointnet2_utils.py:194-240 (GroupingOperation): backward = ``group_points_grad``."""
+
+    @staticmethod
+    def forward(ctx, points, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = points.shape[2]
+        return ops.group_points(points.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return ops.group_points_grad(g.contiguous(), idx, ctx.n), None
+
+
+class _Gather(torch.autograd.Function):
+    """P2/pointnet2_utils.py:68-101 (GatherOperation): backward = ``gather_points_grad``."""
+
+    @staticmethod
+    def forward(ctx, points, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = points.shape[2]
+        return ops.gather_points(points.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return ops.gather_points_grad(g.contiguous(), idx, ctx.n), None
+
+
+def _group(points, idx):
+    if points.dtype == torch.float64:       # float64 evaluation (pwclonet_train_step(dtype=float64)): pure index ops
+        B, C, N = points.shape
+        _, S, K = idx.shape
+        return torch.gather(points.unsqueeze(2).expand(B, C, S, N), 3, idx.long().unsqueeze(1).expand(B, C, S, K))
+    return _Group.apply(points, idx) if torch.is_grad_enabled() else ops.group_points(points.contiguous(), idx)
+
+
+def _gather(points, idx):
+    if points.dtype == torch.float64:
+        return torch.gather(points, 2, idx.long().unsqueeze(1).expand(points.shape[0], points.shape[1], idx.shape[1]))
+    return _Gather.apply(points, idx) if torch.is_grad_enabled() else ops.gather_points(points.contiguous(), idx)
 
 
 def shared_mlp(sd, prefix, x):
@@ -28,8 +77,13 @@ def shared_mlp(sd, prefix, x):
     while f"{prefix}.layer{i}.conv.weight" in sd:
         p = f"{prefix}.layer{i}"
         x = F.conv2d(x, sd[p + ".conv.weight"])
-        x = F.batch_norm(x, sd[p + ".bn.bn.running_mean"], sd[p + ".bn.bn.running_var"],
-                         sd[p + ".bn.bn.weight"], sd[p + ".bn.bn.bias"], False, 0.0, BN_EPS)
+        if _BN_TRAIN:   # batch statistics; running_* updated in place (momentum 0.1, unbiased variance)
+            x = F.batch_norm(x, sd[p + ".bn.bn.running_mean"], sd[p + ".bn.bn.running_var"],
+                             sd[p + ".bn.bn.weight"], sd[p + ".bn.bn.bias"], True, BN_MOMENTUM, BN_EPS)
+            sd[p + ".bn.bn.num_batches_tracked"] += 1
+        else:
+            x = F.batch_norm(x, sd[p + ".bn.bn.running_mean"], sd[p + ".bn.bn.running_var"],
+                             sd[p + ".bn.bn.weight"], sd[p + ".bn.bn.bias"], False, 0.0, BN_EPS)
         x = F.relu(x)
         i += 1
     assert i > 0, f"no layers under {prefix}"
@@ -37,20 +91,21 @@ def shared_mlp(sd, prefix, x):
 
 
 def knn_idx(nsample, xyz, new_xyz):
-    return ops.knn_point_with_dist(nsample, xyz.contiguous(), new_xyz.contiguous())[1]
+    # always from float32 coordinates (the float64 evaluation keeps the float32 path's neighbour lists)
+    return ops.knn_point_with_dist(nsample, xyz.detach().float().contiguous(), new_xyz.detach().float().contiguous())[1]
 
 
 def set_abstraction(sd, prefix, npoint, nsample, xyz, features, taps=None, tap=None):
     """P2/pointnet2_modules.py:179-245 (PointnetSAModulePWCLONet.forward).
     xyz (B,N,3), features (B,C,N) or None -> new_xyz (B,npoint,3), new_features (B,C',npoint)."""
     xyz_flipped = xyz.transpose(1, 2).contiguous()
-    fps = ops.furthest_point_sampling(xyz.contiguous(), npoint)
-    new_xyz = ops.gather_points(xyz_flipped, fps).transpose(1, 2).contiguous()
+    fps = ops.furthest_point_sampling(xyz.detach().float().contiguous(), npoint)
+    new_xyz = _gather(xyz_flipped, fps).transpose(1, 2).contiguous()
     idx = knn_idx(nsample, xyz, new_xyz)
-    grouped_xyz = ops.group_points(xyz_flipped, idx)
+    grouped_xyz = _group(xyz_flipped, idx)
     xyz_diff = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
     if features is not None:
-        x = torch.cat((xyz_diff, ops.group_points(features.contiguous(), idx)), dim=1)
+        x = torch.cat((xyz_diff, _group(features.contiguous(), idx)), dim=1)
     else:
         x = torch.cat((xyz_diff, grouped_xyz), dim=1)
     x = shared_mlp(sd, prefix + ".mlp_module", x)
@@ -69,8 +124,8 @@ def set_upconv(sd, prefix, nsample, xyz2, xyz1, features2, features1, taps=None,
     idx = knn_idx(nsample, xyz1, xyz2)
     if taps is not None and tap:
         taps[tap + ".idx"] = idx
-    x = ops.group_points(features1.contiguous(), idx)
-    grouped_xyz = ops.group_points(xyz1.transpose(1, 2).contiguous(), idx)
+    x = _group(features1.contiguous(), idx)
+    grouped_xyz = _group(xyz1.transpose(1, 2).contiguous(), idx)
     xyz_diff = grouped_xyz - xyz2.transpose(1, 2).unsqueeze(-1)
     x = torch.cat((x, xyz_diff), dim=1)
     x = shared_mlp(sd, prefix + ".mlp", x)
@@ -98,8 +153,8 @@ def cost_volume(sd, prefix, nsample, nsample_q, warped_xyz, warped_points, f2_xy
 
     # first aggregate: neighbours of each (warped) frame-1 point among frame 2
     idx_q = knn_idx(nsample_q, f2_xyz_t, warped_xyz_t)
-    q_xyz = ops.group_points(f2_xyz.contiguous(), idx_q)
-    q_pts = ops.group_points(f2_points.contiguous(), idx_q)
+    q_xyz = _group(f2_xyz.contiguous(), idx_q)
+    q_pts = _group(f2_points.contiguous(), idx_q)
     geo = _geometry10(warped_xyz, q_xyz, nsample_q)
     p_pts = warped_points.unsqueeze(3).repeat(1, 1, 1, nsample_q)
     feat = shared_mlp(sd, prefix + ".mlp_convs", torch.cat((geo, p_pts, q_pts), dim=1))
@@ -110,8 +165,8 @@ def cost_volume(sd, prefix, nsample, nsample_q, warped_xyz, warped_points, f2_xy
 
     # second aggregate: neighbours of each frame-1 point among frame 1
     idx = knn_idx(nsample, warped_xyz_t, warped_xyz_t)
-    c_xyz = ops.group_points(warped_xyz.contiguous(), idx)
-    c_pts = ops.group_points(first.contiguous(), idx)
+    c_xyz = _group(warped_xyz.contiguous(), idx)
+    c_pts = _group(first.contiguous(), idx)
     geo2 = _geometry10(warped_xyz, c_xyz, nsample)
     enc2 = shared_mlp(sd, prefix + ".mlp_conv_xyz_2", geo2)
     p_pts2 = warped_points.unsqueeze(3).repeat(1, 1, 1, nsample)
@@ -170,7 +225,7 @@ def warp(xyz, q, t):
     """PWCLO_utils.py:42-63: q (x) (0,p) (x) q^-1 + t.  xyz (B,3,N), q (B,4,1), t (B,3,1)."""
     B, _, N = xyz.shape
     qi = inv_q(q.squeeze(2)).reshape(B, 4, 1)
-    p = torch.cat((torch.zeros(B, 1, N), xyz), dim=1)
+    p = torch.cat((torch.zeros(B, 1, N, dtype=xyz.dtype), xyz), dim=1)
     r = _hamilton(_hamilton(q.reshape(B, 4, 1), p), qi)
     return r[:, 1:, :] + t
 
@@ -217,6 +272,11 @@ def _normalise_q(q):
 
 @torch.no_grad()
 def pwclonet_forward(sd, xyz_f1, xyz_f2, taps=None):
+    """Eval-mode forward without autograd; see ``_forward``."""
+    return _forward(sd, xyz_f1, xyz_f2, taps)
+
+
+def _forward(sd, xyz_f1, xyz_f2, taps=None):
     """PW/pwclo_net.py:109-207 with points_f1 = points_f2 = None.
     xyz_f1, xyz_f2: (B,3,N) float32 CPU.  Returns pose_params (B,4,7), rows = levels 1..4,
     each [tx,ty,tz,qw,qx,qy,qz]."""
@@ -256,3 +316,53 @@ def pwclonet_forward(sd, xyz_f1, xyz_f2, taps=None):
     rows = [torch.cat((t, _normalise_q(q)), dim=-1).reshape(-1, 1, 7)
             for q, t in ((q1, t1), (q2, t2), (q3, t3), (q4, t4))]
     return torch.cat(rows, dim=1)
+
+
+def pwclonet_loss(pose_params, gt_params, s_param):
+    """slam/training/loss_modules.py:424-544 with ``with_exp_weights`` (:147-197): per level the translation
+    term ``mean(sqrt((t - t_gt)^2 + 1e-10))`` and the rotation term ``mean(sqrt(sum((norm(q) - q_gt)^2) + 1e-10))``
+    combined as ``l_t * exp(-s_0) + s_0 + l_q * exp(-s_1) + s_1``; levels weighted 1.6 / 0.8 / 0.4 / 0.2 from the
+    coarsest (row 3) to the finest (row 0)."""
+    rot_gt, trans_gt = gt_params[:, 3:], gt_params[:, :3]
+    lvl = []
+    for i in range(4):
+        p = pose_params[:, i, :]
+        q = p[:, 3:] / (torch.sqrt(torch.sum(p[:, 3:] * p[:, 3:], dim=-1, keepdim=True) + 1e-10) + 1e-10)
+        l_rot = torch.mean(torch.sqrt(torch.sum((q - rot_gt) * (q - rot_gt), dim=-1, keepdim=True) + 1e-10))
+        l_trans = torch.mean(torch.sqrt((p[:, :3] - trans_gt) * (p[:, :3] - trans_gt) + 1e-10))
+        acc = 0.0
+        for term, s in ((l_trans, s_param[0]), (l_rot, s_param[1])):
+            acc = acc + (term * torch.exp(-s) + s)
+        lvl.append(acc)
+    return 1.6 * lvl[3] + 0.8 * lvl[2] + 0.4 * lvl[1] + 0.2 * lvl[0]
+
+
+def pwclonet_train_step(sd, xyz_f1, xyz_f2, gt_params, s_init=(0.0, -2.5), dtype=torch.float32):
+    """One training-mode forward + loss + backward on CPU (slam/training/trainer.py:624-628 without the optimizer
+    step): batch-statistic BatchNorm (P2/pytorch_utils.py:52-83), dropout of the pose heads OFF
+    (PW/pose_calculator.py:63-65 -- its random stream is device-specific; the fixtures are recorded with the four
+    PoseCalculator modules in eval()).  ``sd`` is updated in place where BatchNorm does (running_mean,
+    running_var, num_batches_tracked) -- for ``dtype=float32``; with ``dtype=torch.float64`` the whole step is evaluated
+    in double precision on copies (FPS and neighbour lists still from the float32 coordinates, so the same lists): the
+    yardstick for how much of a gradient difference is fp32 conditioning (backward through batch-statistic BatchNorm
+    loses ~3 digits: tests/test_gpu_train.py).  Returns ``(pose_params, loss, {key: gradient}, grad_s)``."""
+    global _BN_TRAIN
+    if dtype != torch.float32:
+        sd = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        xyz_f1, xyz_f2, gt_params = xyz_f1.to(dtype), xyz_f2.to(dtype), gt_params.to(dtype)
+    work = dict(sd)
+    leaves = {}
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            leaves[k] = v.detach().clone().requires_grad_(True)
+            work[k] = leaves[k]
+    s_param = torch.tensor(list(s_init), dtype=dtype, requires_grad=True)
+    _BN_TRAIN = True
+    try:
+        with torch.enable_grad():
+            pose = _forward(work, xyz_f1, xyz_f2)
+            loss = pwclonet_loss(pose, gt_params, s_param)
+            loss.backward()
+    finally:
+        _BN_TRAIN = False
+    return pose.detach(), loss.detach(), {k: v.grad for k, v in leaves.items()}, s_param.grad

@@ -17,7 +17,7 @@
  * are pinned by fixtures generated from the imported reference
  * (oracle/gen_golden.py -> tests/golden/).  The nine extension kernels are CUDA
  * and cannot run here: for them this file follows the .cu text and is pinned
- * by hand-derived known-answer cases (tests/test_oracle_ops.py) only --
+ * by hand-derived known-answer cases (tests/test_oracle_cpu.py) only --
  * "parity unpinned" by any reference execution.
  */
 #include <math.h>

@@ -13,6 +13,14 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 
+def _touch(*tensors):
+    """The kernels update running_mean / running_var through raw pointers: bump their version counters so that
+    anything keyed on them (conv1x1._folded) sees the write."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 def _workspace(c, device):
     nbytes = _lib.load().batchnorm_train_workspace_bytes(int(c))
     return torch.empty((nbytes // 8,), dtype=torch.float64, device=device)
@@ -69,7 +77,9 @@ def batch_norm_train(x, bn, relu=False):
         bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu)
+    y = _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu)
+    _touch(rm, rv)
+    return y
 
 
 class _BatchNormReluMaxK(Function):
@@ -122,4 +132,6 @@ def batch_norm_train_relu_max(x, bn):
         bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BatchNormReluMaxK.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)
+    y = _BatchNormReluMaxK.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)
+    _touch(rm, rv)
+    return y

@@ -112,8 +112,11 @@ def conv1x1(x, weight):
 
 def _folded(bn):
     """Per-channel (scale, shift) of an eval-mode BatchNorm, cached on the module until one of its tensors changes
-    (version counters) or moves: a handful of tiny kernels once, not per call."""
-    tensors = (bn.running_mean, bn.running_var, bn.weight, bn.bias)
+    (version counters) or moves: a handful of tiny kernels once, not per call.  The training kernels write the running
+    statistics through raw pointers; they bump the version counters themselves (``touch_running_stats``), and
+    ``pytorch_utils._BN.train()`` drops the cache on every train() / eval() switch, which also covers statistics
+    written by a hipGraph replay of a training step (no Python runs then)."""
+    tensors = (bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.num_batches_tracked)
     key = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors) + (bn.eps,)
     cached = getattr(bn, "_pwclo_folded", None)
     if cached is not None and cached[0] == key:
@@ -128,6 +131,14 @@ def _folded(bn):
         scale, shift = scale.contiguous(), shift.contiguous()
     object.__setattr__(bn, "_pwclo_folded", (key, scale, shift))
     return scale, shift
+
+
+def touch_running_stats(*tensors):
+    """Make a raw-pointer write to BatchNorm buffers visible to torch's version tracking (the folded eval
+    cache keyed on ``_version`` went stale after a training-mode forward that no optimizer step followed)."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
 
 
 def conv1x1_bn_eval(x, conv, bn, relu):
@@ -221,4 +232,6 @@ def bn_relu_conv(x, bn, conv):
         bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BNReluConv.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, conv.weight)
+    y = _BNReluConv.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, conv.weight)
+    touch_running_stats(rm, rv)
+    return y

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, floa
   auto f = [&](float xv, float gv) -> float {
     const float xh = (xv - mu) * is;
     const float yv = xh * g + be;
-    if (MODE == 0) return RELU ? fmaxf(yv, 0.f) : yv;
+    if (MODE == 0) return RELU ? relu_nan(yv) : yv;
     if (RELU && !(yv > 0.f)) gv = 0.f;
     return ((gv - c0) - xh * c1) * (g * is);
   };
@@ -226,14 +226,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_relu_maxk_kernel(int C, i
   int bi = 0;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float yv = fmaxf((xs[e] - mu) * is * g + be, 0.f);
-    if (yv > best) { best = yv; bi = part * 4 + e; bx = xs[e]; }
+    const float yv = relu_nan((xs[e] - mu) * is * g + be);
+    if (yv > best || yv != yv) { best = yv; bi = part * 4 + e; bx = xs[e]; }
   }
 #pragma unroll
   for (int off = 1; off < LPR; off <<= 1) {
     const float ob = __shfl_xor(best, off, 64), ox = __shfl_xor(bx, off, 64);
     const int oi = __shfl_xor(bi, off, 64);
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; bx = ox; }
+    if (ob > best || ob != ob || (ob == best && oi < bi)) { best = ob; bi = oi; bx = ox; }   // a NaN wins, like torch.max
   }
   if (part == 0) {
     const size_t o = plane * (size_t)S + srow;

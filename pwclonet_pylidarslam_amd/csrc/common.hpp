@@ -170,6 +170,12 @@ __device__ __forceinline__ unsigned long long wave_allreduce_min_u64(unsigned lo
   return v;
 }
 
+// ReLU / max that PROPAGATE NaN like torch.relu / torch.max (fmaxf returns the non-NaN operand, so a diverged training
+// run would continue with finite activations and NaN statistics: ADVICE r2).  Used by the module path's training and
+// eval kernels (conv1x1.hip, batchnorm.hip); same instruction count as fmaxf (compare + select vs canonicalise + max).
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float max_nan(float a, float b) { return (a > b || a != a) ? a : b; }
+
 // Number of set bits of `mask` below this lane (wave64 prefix count).
 __device__ __forceinline__ int mbcnt64(unsigned long long mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),

@@ -137,8 +137,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const float4 t = conv_in[16 * mc.m + 4 * s + g];
-            ring[u][s].x = fmaxf(((ring[u][s].x - t.x) * t.y) * t.z + t.w, 0.f);
-            ring[u][s].y = fmaxf(((ring[u][s].y - t.x) * t.y) * t.z + t.w, 0.f);
+            ring[u][s].x = relu_nan(((ring[u][s].x - t.x) * t.y) * t.z + t.w);
+            ring[u][s].y = relu_nan(((ring[u][s].y - t.x) * t.y) * t.z + t.w);
           }
         }
 #pragma unroll
@@ -171,11 +171,11 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
                   const float sc = ep_scale[co], sh = ep_shift[co];
                   v0 = v0 * sc + sh;
                   v1 = v1 * sc + sh;
-                  if (ep_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                  if (ep_relu) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
                 }
                 if (ep_pool > 0) {
-                  float mx = fmaxf(v0, v1);
-                  for (int off = 1; off < (ep_pool >> 1); off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                  float mx = max_nan(v0, v1);
+                  for (int off = 1; off < (ep_pool >> 1); off <<= 1) mx = max_nan(mx, __shfl_xor(mx, off, 64));
                   if (writer && co < Cout) yb[(long long)co * cstride] = mx;
                 } else if (co < Cout) {
                   *reinterpret_cast<float2 *>(yb + (long long)co * cstride) = make_float2(v0, v1);
@@ -265,10 +265,10 @@ __global__ __launch_bounds__(CONV_THREADS, ((RO * RM <= 2 && !XF) ? 4 : 2)) void
         float4 v = pre[u];
         if (XF && r >= Cout && px0 + 4 * q < P) {
           const float4 t = xf[r - Cout];
-          v.x = fmaxf(((v.x - t.x) * t.y) * t.z + t.w, 0.f);
-          v.y = fmaxf(((v.y - t.x) * t.y) * t.z + t.w, 0.f);
-          v.z = fmaxf(((v.z - t.x) * t.y) * t.z + t.w, 0.f);
-          v.w = fmaxf(((v.w - t.x) * t.y) * t.z + t.w, 0.f);
+          v.x = relu_nan(((v.x - t.x) * t.y) * t.z + t.w);
+          v.y = relu_nan(((v.y - t.x) * t.y) * t.z + t.w);
+          v.z = relu_nan(((v.z - t.x) * t.y) * t.z + t.w);
+          v.w = relu_nan(((v.w - t.x) * t.y) * t.z + t.w);
         }
         *reinterpret_cast<float4 *>(dst + (size_t)r * ld + 4 * q) = v;
       }
@@ -395,6 +395,9 @@ static WgradPlan wgrad_plan(int b, int cin, int cout, int p) {
   if (cp < 16 * pl.ph) cp = 16 * pl.ph;      // every phase has at least one 16-pixel sub-chunk
   pl.cp = cp;
   pl.lds = (size_t)2 * rows * (cp + 4) * 4;
+  // with pixel phases the staging area is reused for the phase sums: ph * tgw * 64 float4 (3 -> 4 channels
+  // on <= 128 pixels reserved 7392 bytes for an 8192-byte reduction)
+  if (pl.ph > 1 && pl.lds < (size_t)pl.ph * tgw * 64 * 16) pl.lds = (size_t)pl.ph * tgw * 64 * 16;
   const long long chunks = (long long)b * ceil_div(p, cp);
   const int per_cu = ((size_t)2 * pl.lds <= (size_t)150 * 1024 && pl.ro * pl.rm <= 2) ? 2 : 1;
   const long long want = (long long)conv_grid_x() * per_cu;

@@ -55,9 +55,10 @@ unsigned *device_error_word() {
 // Moves a code posted by a kernel into the calling thread's sticky status.
 static void poll_device_error() {
   if (g_dev_err_host == nullptr) return;
-  const unsigned code = __atomic_load_n(g_dev_err_host, __ATOMIC_ACQUIRE);
+  if (__atomic_load_n(g_dev_err_host, __ATOMIC_ACQUIRE) == 0u) return;     // the common case: one load, no write
+  // take and clear in ONE step: a code a kernel posts between a load and a separate store would be lost
+  const unsigned code = __atomic_exchange_n(g_dev_err_host, 0u, __ATOMIC_ACQ_REL);
   if (code == 0u) return;
-  __atomic_store_n(g_dev_err_host, 0u, __ATOMIC_RELEASE);
   if (code == (unsigned)PWCLO_ECOOP_TIMEOUT)
     set_error(PWCLO_ECOOP_TIMEOUT,
               "furthest_point_sampling(coop): a workgroup waited for its peers beyond the spin bound "

@@ -19,7 +19,19 @@ _USE_HIP_BN = os.environ.get("PWCLO_HIP_BN", "1") != "0"
 _USE_HIP_CONV = os.environ.get("PWCLO_HIP_CONV", "all")
 
 
+def _is_pointwise_on_one_position(conv, x):
+    return (isinstance(conv, nn.Conv1d) and x.dim() == 3 and x.shape[2] == 1 and conv.kernel_size == (1,)
+            and conv.stride == (1,) and conv.dilation == (1,) and conv.groups == 1
+            and (conv.padding == "valid" or conv.padding == (0,)))
+
+
 def _conv(conv, x):
+    if x.is_cuda and _is_pointwise_on_one_position(conv, x):
+        # the pose heads (PW/pose_calculator.py:37-39: Conv1d 64->256, 256->4, 256->3 with bias on a (B, C, 1) tensor) are
+        # plain matrix products; as ``addmm`` their backward is run-to-run deterministic, which the library's
+        # backward-data convolution for this shape is not (tools/train_parity_diag.py: it was the one source of
+        # run-to-run differences in the training step's gradients, amplified ~1e4x by the BatchNorm backward chain)
+        return torch.nn.functional.linear(x[:, :, 0], conv.weight[:, :, 0], conv.bias).unsqueeze(2)
     if _USE_HIP_CONV != "0" and x.is_cuda and _hip_conv.supported(x, conv) and (
             _USE_HIP_CONV == "all" or (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))):
         return _hip_conv.conv1x1(x, conv.weight)
@@ -51,6 +63,13 @@ class _BN(nn.Sequential):
         self.add_module(name + "bn", batch_norm(in_size))
         nn.init.constant_(self[0].weight, 1.0)
         nn.init.constant_(self[0].bias, 0)
+
+    def train(self, mode=True):
+        # the eval path caches the folded (scale, shift) of the running statistics on the BatchNorm module
+        # (conv1x1._folded); a mode switch is the moment statistics may have been rewritten behind torch's back
+        # (raw-pointer kernels, graph replays): drop it
+        self[0].__dict__.pop("_pwclo_folded", None)
+        return super().train(mode)
 
     def forward(self, x):
         bn = self[0]

@@ -42,3 +42,57 @@ def ddp_wrap(model, device=None, process_group=None):
 def gradient_bucket_values(model):
     """Number of fp32 values one step's all-reduce carries (parameters that require grad)."""
     return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def set_reference_train_mode(net, dropout=True):
+    """``net.train()`` as the reference's trainer leaves the model (batch-statistic BatchNorm everywhere,
+    P2/pytorch_utils.py:52-83).  ``dropout=False`` additionally puts the four ``PoseCalculator`` heads -- which
+    hold no BatchNorm, only the two ``F.dropout`` calls of PW/pose_calculator.py:63-65 -- into ``eval()``: the mode
+    the training parity fixtures are recorded in (a dropout stream is not reproducible across devices)."""
+    net.train()
+    if not dropout:
+        heads = [m for m in net.modules() if type(m).__name__ == "PoseCalculator"]
+        assert len(heads) == 4, len(heads)
+        for m in heads:
+            m.eval()
+    return net
+
+
+class TrainStep:
+    """One training step of the data-parallel unit -- ``zero_grad -> forward -> loss -> backward -> optimizer.step``
+    (slam/training/trainer.py:624-628) -- launched eagerly or replayed as ONE hipGraph (``graph=True``; single
+    process only: DDP's bucketed all-reduce is not captured here).  ``step()`` returns the loss tensor (static under
+    the graph: read it before the next replay)."""
+
+    def __init__(self, model, optimizer, xyz_f1, xyz_f2, gt_params, graph=False, warmup=3):
+        self.model, self.opt = model, optimizer
+        self.args = (xyz_f1, xyz_f2, gt_params)
+        self.graph = None
+        if graph:
+            dev = xyz_f1.device
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):                 # allocator / autograd warm-up outside the capture
+                    self._eager()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            self.opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                self.static_loss, _pose, _log = self.model(*self.args)
+                self.static_loss.backward()
+                self.opt.step()
+
+    def _eager(self):
+        self.opt.zero_grad(set_to_none=True)
+        loss, _pose, _log = self.model(*self.args)
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    def step(self):
+        if self.graph is None:
+            return self._eager()
+        self.graph.replay()                             # gradients are overwritten in place by the replay
+        return self.static_loss

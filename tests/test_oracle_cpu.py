@@ -184,6 +184,44 @@ def test_oracle_model_matches_reference_golden(case):
     np.testing.assert_allclose(pose[:, :, 3:].norm(dim=-1).numpy(), 1.0, atol=1e-5)
 
 
+def test_oracle_train_step_matches_reference_train_golden():
+    """``oracle.model.pwclonet_train_step`` (batch-statistic BatchNorm, dropout off, loss + backward) against the
+    values recorded from the imported reference in the same mode (oracle/gen_train_golden.py): forward bit for bit,
+    gradients to the summation-order noise of torch's CPU convolutions, running statistics after the step."""
+    from oracle import gen_golden
+    from oracle.gen_grad_golden import ground_truth
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_n1024_b2.npz"))
+    meta = json.loads(str(z["meta"]))
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_shapes.json")) as f:
+        sd = params.make_state_dict(json.load(f))
+    x1, x2 = gen_golden.case_inputs(meta["case"])
+    pose, loss, grads, gs = M.pwclonet_train_step(sd, x1, x2, ground_truth(x1.shape[0]))
+    np.testing.assert_allclose(pose.numpy(), z["pose_params"], rtol=0, atol=2e-6)
+    assert abs(loss.item() - float(z["loss"])) <= 1e-6 * abs(float(z["loss"]))
+    for k in meta["params"]:
+        ref = z["grad." + k]
+        assert np.abs(grads[k].numpy() - ref).max() <= 5e-5 * np.abs(ref).max(), k
+    np.testing.assert_allclose(gs.numpy(), z["grad_s"], rtol=1e-6)
+    for k in meta["bn_layers"]:
+        np.testing.assert_allclose(sd[k + ".running_mean"].numpy(), z["buf.%s.running_mean" % k], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(sd[k + ".running_var"].numpy(), z["buf.%s.running_var" % k], rtol=1e-6, atol=1e-7)
+        # psa_* run once per frame (PW/pwclo_net.py:140-160): two statistics updates per step there
+        assert int(sd[k + ".num_batches_tracked"]) == int(z["buf.%s.num_batches_tracked" % k])
+    l2 = np.array([grads[k].double().norm().item() for k in meta["all_names"]])
+    np.testing.assert_allclose(l2, z["all_grad_l2"], rtol=1e-4, atol=1e-7 * z["all_grad_l2"].max())
+    # the same step in float64 against the reference model run in float64 (the GPU tests' yardstick)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_shapes.json")) as f:
+        sd = params.make_state_dict(json.load(f))
+    pose, loss, grads, gs = M.pwclonet_train_step(sd, x1, x2, ground_truth(x1.shape[0]), dtype=torch.float64)
+    np.testing.assert_allclose(pose.numpy(), z["pose64"], rtol=0, atol=1e-12)
+    assert abs(loss.item() - float(z["loss64"])) <= 1e-12 * abs(float(z["loss64"]))
+    for k in meta["params"]:
+        ref = z["grad64." + k]
+        assert np.abs(grads[k].numpy() - ref).max() <= 1e-10 * np.abs(ref).max(), k
+    l2 = np.array([grads[k].norm().item() for k in meta["all_names"]])
+    np.testing.assert_allclose(l2, z["all_grad64_l2"], rtol=1e-10)
+
+
 def test_warp_known_answer():
     # SURVEY.md section 7: rotate (1,0,0) by 90 deg about z (scalar-first quaternion), then translate
     q = torch.tensor([[[np.cos(np.pi / 4)], [0.0], [0.0], [np.sin(np.pi / 4)]]], dtype=torch.float32)

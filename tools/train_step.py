@@ -22,7 +22,7 @@ import bench  # noqa: E402
 from pwclonet_pylidarslam_amd import dist_util  # noqa: E402
 from pwclonet_pylidarslam_amd.loss import PWCLONetLossModule  # noqa: E402
 from pwclonet_pylidarslam_amd.pwclonet import PWCLONet  # noqa: E402
-from pwclonet_pylidarslam_amd.training import PWCLONetWithLoss, ddp_wrap, gradient_bucket_values  # noqa: E402
+from pwclonet_pylidarslam_amd.training import PWCLONetWithLoss, TrainStep, ddp_wrap, gradient_bucket_values  # noqa: E402
 
 
 def main():
@@ -59,33 +59,9 @@ def main():
     gt[:, 3:] = torch.nn.functional.normalize(gt[:, 3:] + torch.tensor([1.0, 0, 0, 0]), dim=1)
     gt = gt.to(dev)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss, _pose, _log = model(x1, x2, gt)
-        loss.backward()
-        opt.step()
-        return loss
-
     if a.graph:
         assert world == 1, "--graph is the single-GPU variant (DDP's bucketed all-reduce is not captured here)"
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):                      # allocator / autograd warm-up outside the capture
-                step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
-            static_loss, _pose, _log = model(x1, x2, gt)
-            static_loss.backward()
-            opt.step()
-        eager_step = step
-
-        def step():                                 # grads are overwritten in place by the replay
-            graph.replay()
-            return static_loss
+    step = TrainStep(model, opt, x1, x2, gt, graph=a.graph).step
 
     losses = [step().item() for _ in range(a.warmup)]
     dist_util.fence(dev)
