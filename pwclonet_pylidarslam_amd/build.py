@@ -57,6 +57,22 @@ def _compile(src, force, trace=False):
     return obj, stale
 
 
+def source_stamp():
+    """sha256 (first 16 hex digits) over everything that decides what the kernels do and how much memory they touch:
+    every file of csrc/, the C ABI header and the host-side packing / launch code (fused.py).  Profile artefacts that
+    bench.py reports beside live timings (profiles/pmc_*.json) carry the stamp of the tree they were measured on;
+    bench.py marks them stale when it differs from the running tree's."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+    files += [os.path.join(os.path.dirname(HERE), "include", "pwclo_ops.h"), os.path.join(HERE, "fused.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, jobs=None, trace=False):
     """trace=True builds the developer variant lib/libpwclo_hip_trace.so (-DPWCLO_TRACE: per-workgroup trace hooks,
     tools/wgtrace.py); the product library never carries them."""

@@ -33,7 +33,11 @@ for k, c in sorted(acc.items()):
               "counters": {n: v for n, v in sorted(c.items())}}
 out["_method"] = ("rocprofv3 --pmc (one pass, SQ block) over tools/launch_table.py --reps 1 at batch 32, 2x8192 points; "
                   "sums over all launches of a kernel")
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pwclonet_pylidarslam_amd.build import source_stamp
+out["_source"] = {"csrc_sha16": source_stamp(), "git_head": os.environ.get("GIT_HEAD", "unknown (no .git on the GPU box)")}
 json.dump(out, open(a.out, "w"), indent=1, sort_keys=True)
 for k, v in out.items():
-    if k != "_method" and v["mfma_busy"] > 0.01:
+    if not k.startswith("_") and v["mfma_busy"] > 0.01:
         print(f"{k:48s} launches {v['launches']:3d}  mfma_busy {v['mfma_busy']:.3f}  valu_share {v['valu_share']:.3f}")

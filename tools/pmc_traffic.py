@@ -40,5 +40,9 @@ out["_method"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passe
                   "--reps 1 at batch 32, 2x8192 points; FETCH_SIZE x2 (gfx950 128-byte requests tallied at 64), "
                   "KiB -> bytes; average over the launches of each kernel in the run (all problem sizes it is "
                   "launched at, like bench.py's avg_launch_us)")
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pwclonet_pylidarslam_amd.build import source_stamp
+out["_source"] = {"csrc_sha16": source_stamp(), "git_head": os.environ.get("GIT_HEAD", "unknown (no .git on the GPU box)")}
 json.dump(out, open(a.out, "w"), indent=1, sort_keys=True)
 print("wrote", a.out, len(out) - 1, "kernels")
