@@ -676,7 +676,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "PWCLO-Net forward frame-pairs/sec, 2x8192-pt KITTI pair, batch 32",
+            "metric": "PWCLO-Net forward frame-pairs/sec, 2x%d-pt KITTI pair, batch %d" % (args.npoints, args.batch),
             "value": world * args.batch * args.steps / dt, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",

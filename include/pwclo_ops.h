@@ -416,6 +416,16 @@ void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, int c2, int c
 void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz2, const float *xyz1,
                                    const float *pre, const int *idx, const float *packed_w, float *out,
                                    int wfmt, int packed_floats);
+/* Set-upconv INCLUDING its post-MLP (P2/pointnet2_modules.py:479-515) for up to two jobs that share the queries xyz2, the
+ * coarse points xyz1, the neighbour lists idx and the fine features feat2 (b,s,c2) -- the features and the mask branch of one
+ * refinement level, PW/pose_warp_refinement.py:95-103 -- in ONE launch: out_j (b,s,64) = relu(Wpost_j . [max_k stack_j | feat2]).
+ * pre / packed_w / packed_post / out are HOST arrays of njobs device pointers; packed_w as for upconv_fused_h (fp32 tiles),
+ * packed_post = the one packed post layer (64 + c2 -> 64).  In-lane pooling (a wave tile = 16 queries), c2 in {16,32,64}. */
+void upconv_post_fused_h_kernel_wrapper(int njobs, int b, int n, int s, int k, int c2, const float *xyz2,
+                                        const float *xyz1, const int *idx, const float *feat2,
+                                        const float *const *pre, const float *const *packed_w,
+                                        const float *const *packed_post, float *const *out,
+                                        int packed_floats, int post_floats);
 /* cv_fused_a1 with u (b,s,128) = W1_p . feat1 + b1 and v (b,n,128) = W1_q . feat2. */
 void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz1, const float *u,
                                   const float *xyz2, const float *v, const int *idx,

@@ -321,6 +321,94 @@ __global__ __launch_bounds__(W * 64) void upconv_lane_kernel(UpHArgs a) {
   }
 }
 
+// Set-upconv of a refinement level as ONE launch (round 3): the in-lane kernel above for up to TWO jobs that share
+// queries, coarse points and the neighbour lists (the features and the mask branch of PW/pose_warp_refinement.py:95-103:
+// same xyz, same knn, same fine features, different coarse rows and weights; blockIdx.y = job), with the module's
+// post-MLP (P2/pointnet2_modules.py:508-515: cat(pooled 64, fine features C) -> 64, ReLU) applied to the pooled rows
+// while they are still in registers -- lane j holds query j's pooled channels in the accumulator layout, which IS the
+// next layer's B operand.  Replaces 2 x (upconv + pointwise) launches; values are bit-identical to those (same layer
+// routines, same k order; the max over K is exact in any order).
+struct UpPostArgs {
+  const float *xyz2, *xyz1;   // (B,S,3) fine queries, (B,N,3) coarse points
+  const int *idx;             // (B,S,K)
+  const float *feat2;         // (B,S,16*NB2) fine features, second source of the post-MLP
+  const float *pre[2];        // (B,N,128) = W1_feat feat1 + b1 of each job
+  const float *w[2];          // packed: layer 1 on the diff block (-> 128), layer 2 (128 -> 64)
+  const float *wpost[2];      // packed post layer (64 + 16*NB2 -> 64)
+  float *out[2];              // (B,S,64)
+  int B, N, S, K;
+};
+
+template <int NB2, int W>
+__global__ __launch_bounds__(W * 64) void upconv_lane_post_kernel(UpPostArgs a) {
+  TraceScope trace_scope_(TK_UPCONV_LANE);
+  constexpr int B1 = 8, B2 = 4;
+  constexpr int W1 = layer_floats(1, B1), W2 = layer_floats(B1, B2), WP = layer_floats(B2 + NB2, 4);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  const int job = blockIdx.y;
+  stage_weights(lds_w, a.w[job], W1 + W2);
+  stage_weights(lds_w + W1 + W2, a.wpost[job], WP);
+  __syncthreads();
+  const float *pre = a.pre[job];
+  float *out = a.out[job];
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int tiles_per_cloud = (a.S + 15) / 16;
+  const int ntiles = a.B * tiles_per_cloud;
+  for (int t = blockIdx.x * W + wave_index(); t < ntiles; t += gridDim.x * W) {
+    const int b = t / tiles_per_cloud;
+    const int q = (t - b * tiles_per_cloud) * 16 + j;
+    const bool valid = q < a.S;
+    const unsigned bN = (unsigned)b * (unsigned)a.N;
+    const unsigned row = (unsigned)b * (unsigned)a.S + (unsigned)(valid ? q : a.S - 1);
+    const float *c = at32(a.xyz2, mul24(row, 12u));
+    const float cx = c[0], cy = c[1], cz = c[2];
+    const unsigned slot0 = mul24(row, (unsigned)a.K);
+    f32x4 cat[B2 + NB2][1];
+    auto run_pass = [&](auto first_tag, int k) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      const int nbr = *at32(a.idx, (slot0 + (unsigned)k) * 4u);
+      const unsigned src = bN + (unsigned)nbr;
+      const float *qp = at32(a.xyz1, mul24(src, 12u));
+      f32x4 in[1][1], h1[B1][1], h2[B2][1];
+      in[0][0] = diff_block_h(qp[0] - cx, qp[1] - cy, qp[2] - cz, 0.f, 0.f, 0.f, false, g);
+      const float *prow = at32(pre, (src << 9) + 16u * (unsigned)g);
+#pragma unroll
+      for (int o = 0; o < B1; ++o) h1[o][0] = ld4(prow + 16 * o);
+      mlp_layer_init<1, B1, 1, true, 1>(h1, in, lds_w, lane, [&](int o, int) { return h1[o][0]; });
+      mlp_layer<B1, B2, 1, false>(h2, h1, lds_w + W1, lane);       // ReLU after the pool
+#pragma unroll
+      for (int o = 0; o < B2; ++o) {
+        if (FIRST) {
+          cat[o][0] = h2[o][0];
+        } else {
+          cat[o][0].x = max_bits(cat[o][0].x, h2[o][0].x); cat[o][0].y = max_bits(cat[o][0].y, h2[o][0].y);
+          cat[o][0].z = max_bits(cat[o][0].z, h2[o][0].z); cat[o][0].w = max_bits(cat[o][0].w, h2[o][0].w);
+        }
+      }
+    };
+    run_pass(std::true_type{}, 0);
+#pragma unroll 1
+    for (int k = 1; k < a.K; ++k) run_pass(std::false_type{}, k);
+    // post-MLP on [pooled (64) | fine features (16*NB2)] of the wave's 16 queries
+    const float *frow = at32(a.feat2, row * (unsigned)(64 * NB2) + 16u * (unsigned)g);
+#pragma unroll
+    for (int m = 0; m < NB2; ++m) cat[B2 + m][0] = ld4(frow + 16 * m);
+#pragma unroll
+    for (int o = 0; o < B2; ++o) {
+      f32x4 v = cat[o][0];
+      v.x = relu_bits(v.x); v.y = relu_bits(v.y); v.z = relu_bits(v.z); v.w = relu_bits(v.w);
+      cat[o][0] = v;
+    }
+    f32x4 res[4][1];
+    mlp_layer<B2 + NB2, 4, 1, true>(res, cat, lds_w + W1 + W2, lane);
+    if (valid) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        *reinterpret_cast<f32x4 *>(at32(out, (row << 8) + 64u * o + 16u * (unsigned)g)) = res[o][0];
+    }
+  }
+}
+
 // ---- cost volume a1 / b, hoisted ------------------------------------------------------------------------
 struct CVHArgs {
   const float *xyz1;    // (B,S,3) queries
@@ -573,6 +661,49 @@ extern "C" void upconv_fused_h_kernel_wrapper(int b, int n, int s, int k, const 
   else if (lane_up && t16 > 2048) launch_h<16>(upconv_lane_kernel<16>, attrl, lds, t16, a);   // in-lane max over K
   else launch_h<16>(upconv_h_kernel<8, 1, 16>, attr, lds, tiles_h(b, s, 8, 1), a);
   check_launch("upconv_fused_h");
+}
+
+extern "C" void upconv_post_fused_h_kernel_wrapper(int njobs, int b, int n, int s, int k, int c2, const float *xyz2,
+                                                   const float *xyz1, const int *idx, const float *feat2,
+                                                   const float *const *pre, const float *const *packed_w,
+                                                   const float *const *packed_post, float *const *out,
+                                                   int packed_floats, int post_floats) {
+  if (b <= 0 || s <= 0 || njobs <= 0) return;
+  PWCLO_REQUIRE(njobs <= 2, "upconv_post_fused_h: at most 2 jobs per launch (got %d)", njobs);
+  PWCLO_REQUIRE(k >= 1 && k <= 8, "upconv_post_fused_h: nsample=%d outside [1,8]", k);
+  PWCLO_REQUIRE(c2 == 16 || c2 == 32 || c2 == 64, "upconv_post_fused_h: %d fine feature channels (16, 32 or 64)", c2);
+  PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 8)), "upconv_post_fused_h: batch too large for 32-bit offsets (b=%d)", b);
+  const int nb2 = c2 / 16;
+  PWCLO_REQUIRE(packed_floats == layer_floats(1, 8) + layer_floats(8, 4),
+                "upconv_post_fused_h: packed stack holds %d floats, needs %d (fp32 tiles)", packed_floats,
+                layer_floats(1, 8) + layer_floats(8, 4));
+  PWCLO_REQUIRE(post_floats == layer_floats(4 + nb2, 4), "upconv_post_fused_h: packed post layer holds %d floats, needs %d",
+                post_floats, layer_floats(4 + nb2, 4));
+  UpPostArgs a{xyz2, xyz1, idx, feat2, {pre[0], pre[njobs - 1]}, {packed_w[0], packed_w[njobs - 1]},
+               {packed_post[0], packed_post[njobs - 1]}, {out[0], out[njobs - 1]}, b, n, s, k};
+  const long long t16 = (long long)b * ((s + 15) / 16);
+  const int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4) + layer_floats(4 + nb2, 4));
+  // 16-wave workgroups when every wave slot of the chip gets a tile, 8-wave ones (twice the workgroups) below that
+  const bool wide = t16 * njobs >= 4096;
+  const int W = wide ? 16 : 8;
+  long long gx = (t16 + W - 1) / W;
+  const long long cap = (wide ? 512 : 1024) / njobs;
+  if (gx > cap) gx = cap;
+#define UPP_CASE(NB2)                                                                                         \
+  if (nb2 == NB2) {                                                                                           \
+    static bool attr16 = false, attr8 = false;                                                                \
+    if (wide) {                                                                                               \
+      if (!attr16) { (void)hipFuncSetAttribute((const void *)upconv_lane_post_kernel<NB2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr16 = true; } \
+      hipLaunchKernelGGL((upconv_lane_post_kernel<NB2, 16>), dim3((unsigned)gx, njobs), dim3(16 * 64), lds, current_stream(), a); \
+    } else {                                                                                                  \
+      if (!attr8) { (void)hipFuncSetAttribute((const void *)upconv_lane_post_kernel<NB2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr8 = true; } \
+      hipLaunchKernelGGL((upconv_lane_post_kernel<NB2, 8>), dim3((unsigned)gx, njobs), dim3(8 * 64), lds, current_stream(), a); \
+    }                                                                                                         \
+    check_launch("upconv_post_fused_h");                                                                      \
+    return;                                                                                                   \
+  }
+  UPP_CASE(1) UPP_CASE(2) UPP_CASE(4)
+#undef UPP_CASE
 }
 
 extern "C" void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz1, const float *u,

@@ -624,6 +624,32 @@ class FusedUpconvHoisted:
         return self.post(pooled, feat2)
 
 
+def upconv_post_supported(ups, B, S):
+    """The one-launch form (csrc/fused_hoisted.hip: upconv_lane_post_kernel) exists for fp32 tiles and pays once the
+    jobs' 16-query tiles fill the chip's wave slots at least once (refinement levels 2 and 1 at batch 32)."""
+    return (os.environ.get("PWCLO_UP_POST", "1") != "0" and all(u.wfmt == WFMT_F32 for u in ups)
+            and len(ups) * B * ((S + 15) // 16) >= 4096)
+
+
+def run_upconv_post(ups, xyz2, xyz1, feat2, pres, idx):
+    """``[u(xyz2, xyz1, feat2, pre, idx) for u, pre in zip(ups, pres)]`` for 1-2 ``FusedUpconvHoisted`` that share every
+    input but the hoisted coarse rows: one launch, post-MLP included."""
+    import ctypes
+    B, S, _ = xyz2.shape
+    N, K = xyz1.shape[1], idx.shape[2]
+    n = len(ups)
+    c2 = feat2.shape[2]
+    outs = [torch.empty((B, S, 64), dtype=torch.float32, device=xyz2.device) for _ in ups]
+    pa = lambda v: (ctypes.c_void_p * n)(*v)
+    _lib.annotate(family="mlp", kernel="upconv_lane_post_kernel<%d, %d>" % (c2 // 16, 16 if n * B * ((S + 15) // 16) >= 4096 else 8),
+                  flops=sum(2.0 * B * S * (K * (u.macs - 64 * 128) + u.post.macs) for u in ups),
+                  bytes=4.0 * n * B * (S * K * (1 + 3 + 128) + 3 * S + S * c2 + 64 * S))
+    _lib.call("upconv_post_fused_h_kernel_wrapper", xyz2.device, n, B, N, S, K, c2, _p(xyz2), _p(xyz1), _p(idx), _p(feat2),
+              pa([_p(t) for t in pres]), pa([_p(u.packed) for u in ups]), pa([_p(u.post.packed) for u in ups]),
+              pa([_p(o) for o in outs]), ups[0].packed.numel(), ups[0].post.packed.numel())
+    return outs
+
+
 class FusedCostVolumeHoisted:
     """``CostVolume``: centre / neighbour feature parts of mlp_convs[0] and mlp3_convs[0] hoisted."""
 
@@ -795,17 +821,23 @@ class FusedPWCLONet:
         if self.hoist:          # all per-point partial products of this level in one launch
             pre_f, pre_m, u, v, u2 = br.hold(*run_linear_jobs(
                 d["up_f"].jobs(emb_prev) + d["up_m"].jobs(mask_prev) + d["cv"].jobs(f1, f2)))
-        with br.fork(1):        # set-upconv of the features ...
-            up_feat = br.hold(d["up_f"](x1, x1_prev, f1, pre_f if self.hoist else emb_prev, idx_up))
-        with br.fork(2):        # ... and of the mask are independent of the warp -> cost-volume chain
-            up_mask = br.hold(d["up_m"](x1, x1_prev, f1, pre_m if self.hoist else mask_prev, idx_up))
+        one_launch = self.hoist and upconv_post_supported((d["up_f"], d["up_m"]), x1.shape[0], x1.shape[1])
+        if one_launch:          # both set-upconvs and their post-MLPs as one launch, beside the warp -> cost-volume chain
+            with br.fork(1):
+                up_feat, up_mask = br.hold(*run_upconv_post((d["up_f"], d["up_m"]), x1, x1_prev, f1, (pre_f, pre_m), idx_up))
+        else:
+            with br.fork(1):        # set-upconv of the features ...
+                up_feat = br.hold(d["up_f"](x1, x1_prev, f1, pre_f if self.hoist else emb_prev, idx_up))
+            with br.fork(2):        # ... and of the mask are independent of the warp -> cost-volume chain
+                up_mask = br.hold(d["up_m"](x1, x1_prev, f1, pre_m if self.hoist else mask_prev, idx_up))
         warped = br.hold(quat_warp_pm(x1, q_prev, t_prev))
         if taps is not None:
             taps[tap + ".warped"] = warped
         resid = br.hold(d["cv"](warped, x2, u, v, u2, taps=taps, tap=tap + ".cv") if self.hoist else
                         d["cv"](warped, f1, x2, f2, taps=taps, tap=tap + ".cv"))
         br.join(1)
-        br.join(2)
+        if not one_launch:
+            br.join(2)
         emb = d["pred_f"](f1, resid, up_feat)
         mask = up_mask if d["last"] else d["pred_m"](up_mask, emb, f1)
         q, t = d["head"](emb, mask, pose, row, q_prev, t_prev)

@@ -105,6 +105,29 @@ def test_fused_set_upconv(cuda, c2, n2, n1, hoist):
     close(pm(out), ref)
 
 
+@pytest.mark.parametrize("c2,n2,n1,b,njobs", [(16, 2048, 1024, 3, 2), (32, 1024, 256, 4, 2), (64, 333, 90, 2, 2),
+                                              (16, 16403, 700, 2, 2), (32, 77, 40, 1, 1)])
+def test_fused_set_upconv_one_launch_with_post_mlp(cuda, c2, n2, n1, b, njobs):
+    """csrc/fused_hoisted.hip upconv_lane_post_kernel: both set-upconvs of a refinement level (features and mask branch:
+    same queries, coarse points, neighbour lists and fine features) INCLUDING their post-MLPs in one launch -- against
+    the oracle, and bit for bit against the separate launches (upconv + pointwise per branch) it replaces."""
+    names = ["pose_warp_refinement_2.setupconv_features", "pose_warp_refinement_2.setupconv_mask"][:njobs]
+    mods, osds = zip(*[filled(PointnetFPModulePWCLONet(nsample=8, mlp=[64, 128, 64], post_mlp=[64 + c2, 64], radius=0.2,
+                                                       knn=True, use_xyz=True, bn=True), nm) for nm in names])
+    xyz2, xyz1 = cloud(3, b, n2), cloud(4, b, n1)
+    g = torch.Generator().manual_seed(5)
+    f2 = torch.randn(b, c2, n2, generator=g)
+    f1s = [torch.randn(b, 64, n1, generator=g) for _ in names]
+    idx = O.knn_point_with_dist(8, xyz1, xyz2)[1]
+    ups = [fused.FusedUpconvHoisted(m.to(cuda)) for m in mods]
+    pres = fused.run_linear_jobs([u.jobs(pm(f1).to(cuda))[0] for u, f1 in zip(ups, f1s)])
+    args = (xyz2.to(cuda), xyz1.to(cuda), pm(f2).to(cuda))
+    outs = fused.run_upconv_post(ups, *args, pres, idx.to(cuda))
+    for u, pre, out, osd, nm, f1 in zip(ups, pres, outs, osds, names, f1s):
+        close(pm(out), M.set_upconv(osd, nm, 8, xyz2, xyz1, f2, f1))
+        assert torch.equal(out, u(*args, pre, idx.to(cuda))), nm
+
+
 @pytest.mark.parametrize("nq,ns,c,s,n", [(32, 4, 64, 256, 256), (6, 4, 64, 256, 256), (6, 4, 32, 512, 512),
                                           (6, 4, 16, 301, 280), (32, 4, 64, 70, 90), (6, 4, 32, 5, 9),
                                           (8, 4, 64, 37, 64),
