@@ -431,6 +431,16 @@ void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const float *xyz1,
                                   const float *xyz2, const float *v, const int *idx,
                                   const float *packed_w, float *pix, int pix_slots, int wfmt,
                                   int packed_floats);
+/* cv_fused_a1_h + cv_fused_a2 for nsample_q = 6 as ONE kernel (in-lane softmax, a wave tile = 16 queries): the per-pixel
+ * (b,s,6,64) buffer between the two stages does not exist; first (b,s,64) is the first aggregate (PW/costvolume.py:139-141).
+ * packed_a1 / packed_a2: the two stages' packed stacks as for the separate kernels (fp32 tiles; both LDS resident).
+ * packed_v2 (may be NULL, then v2 must be NULL): the one packed layer 64 -> 128 of cv_b's neighbour partial product;
+ * v2 (b,s,128) = W_f . first is then written as well (replaces that linear_jobs launch).  Bit-identical to the separate
+ * kernels. */
+void cv_fused_a_lane6_kernel_wrapper(int b, int n, int s, const float *xyz1, const float *u, const float *xyz2,
+                                     const float *v, const int *idx, const float *packed_a1, const float *packed_a2,
+                                     const float *packed_v2, float *first, float *v2, int a1_floats, int a2_floats,
+                                     int v2_floats);
 /* cv_fused_b with u2 (b,s,128) = W_p . feat1 + b, v2 (b,s,128) = W_f . first, first (b,s,64). */
 void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xyz1, const float *u2,
                                  const float *v2, const float *first, const int *idx,

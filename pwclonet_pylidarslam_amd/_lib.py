@@ -85,6 +85,7 @@ SIGNATURES = {
     "upconv_fused_h_kernel_wrapper": ([_i] * 4 + [_F] * 6 + [_i] * 2, None),
     "upconv_post_fused_h_kernel_wrapper": ([_i] * 6 + [_F] * 4 + [ctypes.POINTER(ctypes.c_void_p)] * 4 + [_i] * 2, None),
     "cv_fused_a1_h_kernel_wrapper": ([_i] * 4 + [_F] * 7 + [_i] * 3, None),
+    "cv_fused_a_lane6_kernel_wrapper": ([_i] * 3 + [_F] * 10 + [_i] * 3, None),
     "cv_fused_b_h_kernel_wrapper": ([_i] * 3 + [_F] * 7 + [_i] * 2, None),
     "odom_rows_to_transforms_kernel_wrapper": ([_i, _i, _F, _F, _i], None),
     "odom_accumulate_kernel_wrapper": ([_i, _F, _F, _F], None),

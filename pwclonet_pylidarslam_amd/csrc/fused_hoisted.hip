@@ -539,6 +539,151 @@ __global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
   }
 }
 
+// ---- first aggregate of the cost volume for K = 6 as ONE kernel (round 3) ----------------------------------------------
+// cv_a1_h (per-pixel feature stack [geo | u[s] + v[n]] -> 128 -> 64 -> 64) used to write its 64-channel result per
+// pixel, (B,S,6,64), for cv_a2_lane6 to read back and run [enc(geo) | feat] -> 128 -> 64 -> softmax over the six
+// neighbours.  Both stages work on the SAME pixel, so here a wave tile = 16 consecutive queries (lane j <-> query j),
+// pass `grp` runs neighbours 2*grp, 2*grp+1 of those queries through BOTH stacks in registers and merges the softmax with
+// the running-maximum form (cv_a2_lane6_kernel): no per-pixel buffer (level 1: 100 MB written + 100 MB read per call), one
+// launch instead of two, the centre rows u[s] read once per pass instead of once per pixel.  All 161.8 KB of both stages'
+// packed weights are LDS resident (the device's limit is 160 KiB = 163.8 KB).  Every layer runs the same routine on the
+// same operands in the same k order as the two kernels it replaces: results are bit-identical to them.
+// V2: the partial product v2 = W_f . first that cv_b gathers per neighbour (linear_jobs' job_v2) is formed in the epilogue
+// while `first` is in registers -- lane j holds query j's 64 channels in the accumulator layout, i.e. as a B operand; its
+// 32 weight tiles do not fit LDS any more and are read from global memory (L2 resident: 33 KB shared by every wave).
+struct CVLaneArgs {
+  const float *xyz1;    // (B,S,3) queries (warped frame-1 points)
+  const float *u;       // (B,S,128) centre partial product of a1's first layer (bias included)
+  const float *xyz2;    // (B,N,3) candidates
+  const float *v;       // (B,N,128) neighbour partial product
+  const int *idx;       // (B,S,6)
+  const float *w_a1;    // packed: geometry block (-> 128), 128 -> 64, 64 -> 64
+  const float *w_a2;    // packed: mlp_conv_xyz_1 (geo -> 64), 128 -> 128, 128 -> 64
+  const float *w_v2;    // packed single layer 64 -> 128 (no activation), or nullptr
+  float *first;         // (B,S,64)
+  float *v2;            // (B,S,128) when w_v2
+  int B, N, S;
+};
+
+__device__ __forceinline__ f32x4 geometry_block_std(const float *p, const float *q, int g) {   // fused_layers.hip: geometry_block
+  const float px = p[0], py = p[1], pz = p[2], qx = q[0], qy = q[1], qz = q[2];
+  const float dx = qx - px, dy = qy - py, dz = qz - pz;
+  const float euc = sqrtf(((dx * dx + dy * dy) + dz * dz) + 1e-20f);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (g == 0) v = f32x4{px, py, pz, qx};
+  if (g == 1) v = f32x4{qy, qz, dx, dy};
+  if (g == 2) v = f32x4{dz, euc, 0.f, 0.f};
+  return v;
+}
+
+template <int W, bool V2>
+__global__ __launch_bounds__(W * 64) void cv_a_lane6_kernel(CVLaneArgs a) {
+  TraceScope trace_scope_(TK_CV_A2_LANE6);
+  constexpr int P = 2, PASSES = 3;
+  constexpr int A1 = layer_floats(1, 8), A2 = layer_floats(8, 4), A3 = layer_floats(4, 4);
+  constexpr int WX = layer_floats(1, 4), W1 = layer_floats(8, 8), W2 = layer_floats(8, 4);
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  float *lds_a2 = lds_w + A1 + A2 + A3;
+  stage_weights(lds_w, a.w_a1, A1 + A2 + A3);
+  stage_weights(lds_a2, a.w_a2, WX + W1 + W2);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int tiles_per_cloud = (a.S + 15) / 16;
+  const int ntiles = a.B * tiles_per_cloud;
+  for (int t = blockIdx.x * W + wave_index(); t < ntiles; t += gridDim.x * W) {
+    const int b = t / tiles_per_cloud;
+    const int q = (t - b * tiles_per_cloud) * 16 + j;
+    const bool valid = q < a.S;
+    const unsigned row = (unsigned)b * (unsigned)a.S + (unsigned)(valid ? q : a.S - 1);
+    const unsigned bN = (unsigned)b * (unsigned)a.N;
+    const float *centre = at32(a.xyz1, mul24(row, 12u));
+    f32x4 mrun[4], drun[4], nrun[4];
+    auto run_pass = [&](auto first_tag, int pass) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      f32x4 geo_h[1][P], geo[1][P], h1[8][P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const unsigned slot = mul24(row, 6u) + (unsigned)(P * pass + p);
+        const int nbr = *at32(a.idx, slot * 4u);
+        const unsigned src = bN + (unsigned)nbr;
+        const float *qp = at32(a.xyz2, mul24(src, 12u));
+        geo_h[0][p] = geometry_block_h(centre, qp, g);
+        geo[0][p] = geometry_block_std(centre, qp, g);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) h1[o][p] = ld_group<false>(a.v, src, 128u, o, g);
+      }
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const f32x4 uc = ld_group<false>(a.u, row, 128u, o, g);
+#pragma unroll
+        for (int p = 0; p < P; ++p) h1[o][p] = uc + h1[o][p];
+      }
+      f32x4 h2[4][P], cat[8][P];
+      {   // stage a1: the per-pixel feature (what cv_a1_h stored)
+        mlp_layer_init<1, 8, P, true, 3>(h1, geo_h, lds_w, lane, [&](int o, int p) { return h1[o][p]; });
+        mlp_layer<8, 4, P, true>(h2, h1, lds_w + A1, lane);
+        f32x4 h3[4][P];
+        mlp_layer<4, 4, P, true>(h3, h2, lds_w + A1 + A2, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int p = 0; p < P; ++p) cat[4 + m][p] = h3[m][p];
+      }
+      {   // stage a2: position encoding, attention logits
+        f32x4 enc[4][P];
+        mlp_layer<1, 4, P, true>(enc, geo, lds_a2, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int p = 0; p < P; ++p) cat[m][p] = enc[m][p];
+      }
+      f32x4 g1[8][P], g2[4][P];
+      mlp_layer<8, 8, P, true>(g1, cat, lds_a2 + WX, lane);
+      mlp_layer<8, 4, P, true>(g2, g1, lds_a2 + WX + W1, lane);
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x0 = g2[o][0][c], x1 = g2[o][1][c];                     // post-ReLU: >= 0
+          const float m = max_bits(x0, x1);
+          const float e0 = exp_nonpos(x0 - m), e1 = exp_nonpos(x1 - m);
+          const float d = e0 + e1;
+          const float n = e0 * cat[4 + o][0][c] + e1 * cat[4 + o][1][c];
+          if (FIRST) {
+            mrun[o][c] = m; drun[o][c] = d; nrun[o][c] = n;
+          } else {
+            const float mm = max_bits(mrun[o][c], m);
+            const float fa = exp_nonpos(mrun[o][c] - mm), fb = exp_nonpos(m - mm);
+            mrun[o][c] = mm;
+            drun[o][c] = drun[o][c] * fa + d * fb;
+            nrun[o][c] = nrun[o][c] * fa + n * fb;
+          }
+        }
+    };
+    run_pass(std::true_type{}, 0);
+#pragma unroll 1
+    for (int pass = 1; pass < PASSES; ++pass) run_pass(std::false_type{}, pass);
+    f32x4 res[4][1];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) res[o][0][c] = div_ge1(nrun[o][c], drun[o][c]);
+    if (valid) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        *reinterpret_cast<f32x4 *>(at32(a.first, (row << 8) + 64u * o + 16u * (unsigned)g)) = res[o][0];
+    }
+    if constexpr (V2) {
+      f32x4 pv[8][1];
+      mlp_layer<4, 8, 1, false>(pv, res, a.w_v2, lane);      // weights from global memory (see the header comment)
+      if (valid) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) st_group<false>(a.v2, row, 128u, o, g, pv[o][0]);
+      }
+    }
+  }
+}
+
 // ---- launch helpers ----------------------------------------------------------------------------------------
 template <int W, typename Kern, typename Args>
 static void launch_h(Kern kern, bool &attr_set, int lds_bytes, long long ntiles, const Args &a) {
@@ -546,7 +691,7 @@ static void launch_h(Kern kern, bool &attr_set, int lds_bytes, long long ntiles,
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  // once per kernel: the largest any configuration can ask for
     attr_set = true;
   }
-  static const int rounds = fh_tuning("PWCLO_FL_ROUNDS", 2);
+  static const int rounds = fh_tuning("PWCLO_FL_ROUNDS", 1);
   const int per_cu = (lds_bytes > 80 * 1024 || W > 8) ? 1 : 2;
   long long grid = (ntiles + W - 1) / W;
   if (grid > 256LL * per_cu * rounds) grid = 256LL * per_cu * rounds;
@@ -743,6 +888,28 @@ extern "C" void cv_fused_a1_h_kernel_wrapper(int b, int n, int s, int k, const f
   else if (kp == 16) launch_h<16>(cv_a1_h_kernel<16, 1, 16>, a16, lds, tiles_h(b, s, 16, 1), a);
   else launch_h<16>(cv_a1_h_kernel<8, 1, 16>, a8, lds, tiles_h(b, s, 8, 1), a);
   check_launch("cv_fused_a1_h");
+}
+
+extern "C" void cv_fused_a_lane6_kernel_wrapper(int b, int n, int s, const float *xyz1, const float *u, const float *xyz2,
+                                                const float *v, const int *idx, const float *packed_a1,
+                                                const float *packed_a2, const float *packed_v2, float *first,
+                                                float *v2, int a1_floats, int a2_floats, int v2_floats) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(rows_fit_32bit((long long)b * max(n, s * 6)), "cv_fused_a_lane6: batch too large for 32-bit offsets (b=%d)", b);
+  constexpr int fa1 = layer_floats(1, 8) + layer_floats(8, 4) + layer_floats(4, 4);
+  constexpr int fa2 = layer_floats(1, 4) + layer_floats(8, 8) + layer_floats(8, 4);
+  PWCLO_REQUIRE(a1_floats == fa1 && a2_floats == fa2, "cv_fused_a_lane6: packed stacks hold %d / %d floats, need %d / %d (fp32 tiles)",
+                a1_floats, a2_floats, fa1, fa2);
+  PWCLO_REQUIRE((packed_v2 == nullptr) == (v2 == nullptr) && (packed_v2 == nullptr || v2_floats == layer_floats(4, 8)),
+                "cv_fused_a_lane6: the v2 layer needs both its packed weights (%d floats, got %d) and an output", layer_floats(4, 8), v2_floats);
+  CVLaneArgs a{xyz1, u, xyz2, v, idx, packed_a1, packed_a2, packed_v2, first, v2, b, n, s};
+  constexpr int lds = 4 * (fa1 + fa2);
+  static_assert(lds <= 160 * 1024, "both stages' weights must fit the 160 KiB of LDS");
+  const long long t16 = (long long)b * ((s + 15) / 16);
+  static bool attr = false, attr_v = false;
+  if (packed_v2 != nullptr) launch_h<8>(cv_a_lane6_kernel<8, true>, attr_v, lds, t16, a);
+  else launch_h<8>(cv_a_lane6_kernel<8, false>, attr, lds, t16, a);
+  check_launch("cv_fused_a_lane6");
 }
 
 extern "C" void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xyz1, const float *u2,

@@ -728,7 +728,7 @@ static void launch_persistent(Kern kern, bool &attr_set, int lds_bytes, long lon
   }
   // Workgroups beyond one resident set queue behind it; >1 "rounds" keeps the kernel balanced when
   // part of the chip is held by another stream's kernels (e.g. the other in-flight batch's FPS).
-  static const int rounds = fl_tuning("PWCLO_FL_ROUNDS", 2);
+  static const int rounds = fl_tuning("PWCLO_FL_ROUNDS", 1);
   const int per_cu = (lds_bytes > 80 * 1024 || W > 8) ? 1 : 2;
   long long grid = (ntiles + W - 1) / W;
   if (grid > 256LL * per_cu * rounds) grid = 256LL * per_cu * rounds;

@@ -702,6 +702,10 @@ class FusedCostVolumeHoisted:
         if idx_q is None:
             idx_q = knn(kq, xyz2, xyz1)
         kp = self.kp
+        merged = (kp == 6 and kq == 6 and self.wfmt == WFMT_F32 and self.wfmt_a2 == WFMT_F32 and B * ((S + 15) // 16) > 1024
+                  and os.environ.get("PWCLO_LANE6", "1") != "0" and os.environ.get("PWCLO_CV_MERGED", "1") != "0")
+        if merged:
+            return self._merged(xyz1, xyz2, u, v, u2, idx_q, idx, taps, tap)
         pix = torch.empty((B, S * kp, 64), dtype=torch.bfloat16 if self.wfmt == WFMT_BF16 else torch.float32, device=dev)
         _lib.annotate(family="mlp", kernel=_kname("cv_a1_h_kernel<%d, 1, 16>" % kp, self.wfmt),
                       flops=2.0 * B * S * kq * (self.macs_a1 - 2 * c * 128),
@@ -719,6 +723,33 @@ class FusedCostVolumeHoisted:
         if taps is not None:
             taps[tap + ".idx_q"], taps[tap + ".idx"] = idx_q, idx
         (v2,) = run_linear_jobs([(self.job_v2, first)])
+        return self._second(xyz1, u2, v2, first, idx)
+
+    def _merged(self, xyz1, xyz2, u, v, u2, idx_q, idx, taps, tap):
+        """First aggregate as ONE kernel (csrc/fused_hoisted.hip: cv_a_lane6_kernel; refinement levels 2 and 1 at batch
+        32): no per-pixel buffer, and -- unless PWCLO_CV_V2=0 -- cv_b's neighbour partial product v2 from its epilogue."""
+        B, S, _ = xyz1.shape
+        N, dev, k = xyz2.shape[1], xyz1.device, self.nsample
+        fold_v2 = os.environ.get("PWCLO_CV_V2", "1") != "0" and not self.job_v2.out_bf16
+        first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
+        v2 = torch.empty((B, S, 128), dtype=torch.float32, device=dev) if fold_v2 else None
+        _lib.annotate(family="mlp", kernel="cv_a_lane6_kernel<8, %s>" % ("true" if fold_v2 else "false"),
+                      flops=2.0 * B * S * (6 * (self.macs_a1 - 2 * self.c * 128 + self.macs_a2) + (64 * 128 if fold_v2 else 0)),
+                      bytes=4.0 * B * (S * 6 * (1 + 3 + 128) + S * (3 + 3 * 128 + 64 + (128 if fold_v2 else 0))))
+        _lib.call("cv_fused_a_lane6_kernel_wrapper", dev, B, N, S, _p(xyz1), _p(u), _p(xyz2), _p(v), _p(idx_q),
+                  _p(self.w_a1), _p(self.w_a2), _p(self.job_v2.packed) if fold_v2 else 0, _p(first), _p(v2),
+                  self.w_a1.numel(), self.w_a2.numel(), self.job_v2.packed.numel() if fold_v2 else 0)
+        if idx is None:
+            idx = knn(k, xyz1, xyz1)
+        if taps is not None:
+            taps[tap + ".idx_q"], taps[tap + ".idx"] = idx_q, idx
+        if not fold_v2:
+            (v2,) = run_linear_jobs([(self.job_v2, first)])
+        return self._second(xyz1, u2, v2, first, idx)
+
+    def _second(self, xyz1, u2, v2, first, idx):
+        B, S, _ = xyz1.shape
+        dev, k, c = xyz1.device, self.nsample, self.c
         out = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
         _lib.annotate(family="mlp", kernel=_kname("cv_b_h_kernel<4, 1, %d>" % (4 if B * ((S * 4 + 15) // 16) <= 2048 else 16), self.wfmt),
                       flops=2.0 * B * S * k * (self.macs_b - (c + 64) * 128),

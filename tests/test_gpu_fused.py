@@ -154,6 +154,29 @@ def test_fused_cost_volume(cuda, nq, ns, c, s, n, hoist):
     close(pm(out), ref)
 
 
+@pytest.mark.parametrize("c,s,n,b", [(16, 8203, 8190, 2), (32, 1024, 1024, 17), (64, 2048, 2000, 9)])
+def test_fused_cost_volume_first_aggregate_as_one_kernel(cuda, monkeypatch, c, s, n, b):
+    """csrc/fused_hoisted.hip cv_a_lane6_kernel (cv_a1 + cv_a2 for K = 6 in one kernel, optionally with cv_b's neighbour
+    partial product v2 from its epilogue): bit for bit the result of the separate kernels it replaces, for both settings of
+    the v2 fold."""
+    name = "pose_warp_refinement_1.cost_volume"
+    mod, _ = filled(CostVolume(nsample=4, nsample_q=6, in_channel1=c, in_channel2=c, mlp1=[128, 64, 64], mlp2=[128, 64]), name)
+    g = torch.Generator().manual_seed(16)
+    x1, x2 = cloud(17, b, s).to(cuda), cloud(18, b, n).to(cuda)
+    p1, p2 = torch.randn(b, s, c, generator=g).to(cuda), torch.randn(b, n, c, generator=g).to(cuda)
+    cv = fused.FusedCostVolumeHoisted(mod.to(cuda))
+    u, v, u2 = fused.run_linear_jobs(cv.jobs(p1, p2))
+    idx_q, idx = fused.knn(6, x2, x1), fused.knn(4, x1, x1)
+    outs = {}
+    for key, env in (("separate", {"PWCLO_CV_MERGED": "0"}), ("merged", {"PWCLO_CV_MERGED": "1", "PWCLO_CV_V2": "0"}),
+                     ("merged+v2", {"PWCLO_CV_MERGED": "1", "PWCLO_CV_V2": "1"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        outs[key] = cv(x1, x2, u, v, u2, idx_q=idx_q, idx=idx)
+    assert torch.equal(outs["merged"], outs["separate"])
+    assert torch.equal(outs["merged+v2"], outs["separate"])
+
+
 def test_fused_pointwise_and_pose_head(cuda):
     g = torch.Generator().manual_seed(9)
     for chans in ((64, 64, 64), (32, 64, 64), (16, 64, 64), (64, 64, 32), (128, 64)):
