@@ -78,39 +78,51 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, 
 constexpr int GP_LDS_MAXN = 4096;     // 8 channels x 4096 floats = 128 KiB of LDS
 constexpr int GP_CHUNK = 4096;        // outputs per channel and workgroup (16 per thread)
 
-__global__ __launch_bounds__(GP_THREADS) void group_points_lds_kernel(int c, int n, int P,
-                                                                      const float *__restrict__ points,
-                                                                      const int *__restrict__ idx,
-                                                                      float *__restrict__ out) {
+// T threads per workgroup; the workgroup streams positions [blockIdx.x * per_wg, +per_wg) of its channel slice.
+// NT: non-temporal stores (the output is never re-read by this kernel).
+template <int T, bool NT>
+__global__ __launch_bounds__(T) void group_points_lds_kernel(int c, int n, int P, int per_wg,
+                                                             const float *__restrict__ points,
+                                                             const int *__restrict__ idx,
+                                                             float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float rows[];   // [GP_CH_PER_BLOCK][n]
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * GP_CH_PER_BLOCK;
   const int nch = min(GP_CH_PER_BLOCK, c - c0);
   const float *src = points + ((size_t)b * c + c0) * n;
   const int total = nch * n;
+  const int *ib = idx + (size_t)b * P;
+  const int p_begin = blockIdx.x * per_wg;
+  const int p_end = min(P, p_begin + per_wg);
+  // the first indices are requested before the rows are staged: their latency hides under the copy
+  int p = p_begin + threadIdx.x * 4;
+  int4 ii = make_int4(0, 0, 0, 0);
+  if (p < p_end) ii = *reinterpret_cast<const int4 *>(ib + p);
   if ((n & 3) == 0) {
-    for (int i = threadIdx.x * 4; i < total; i += GP_THREADS * 4)
+    for (int i = threadIdx.x * 4; i < total; i += T * 4)
       *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
   } else {
-    for (int i = threadIdx.x; i < total; i += GP_THREADS) rows[i] = src[i];
+    for (int i = threadIdx.x; i < total; i += T) rows[i] = src[i];
   }
   __syncthreads();
-  const int *ib = idx + (size_t)b * P;
   float *ob = out + ((size_t)b * c + c0) * P;
-  const int p_end = min(P, (int)(blockIdx.x + 1) * GP_CHUNK);
-  for (int p = blockIdx.x * GP_CHUNK + threadIdx.x * 4; p < p_end; p += GP_THREADS * 4) {
-    const int4 ii = *reinterpret_cast<const int4 *>(ib + p);
+  for (; p < p_end; p += T * 4) {
+    const int pn = p + T * 4;
+    int4 inext = ii;
+    if (pn < p_end) inext = *reinterpret_cast<const int4 *>(ib + pn);
 #pragma unroll
     for (int l = 0; l < GP_CH_PER_BLOCK; ++l) {
       if (l < nch) {
         const float *row = rows + l * n;
-        float *o = ob + (size_t)l * P + p;
-        __builtin_nontemporal_store(row[ii.x], o + 0);
-        __builtin_nontemporal_store(row[ii.y], o + 1);
-        __builtin_nontemporal_store(row[ii.z], o + 2);
-        __builtin_nontemporal_store(row[ii.w], o + 3);
+        typedef float gp_f32x4 __attribute__((ext_vector_type(4)));
+        gp_f32x4 v;
+        v.x = row[ii.x]; v.y = row[ii.y]; v.z = row[ii.z]; v.w = row[ii.w];
+        gp_f32x4 *o = reinterpret_cast<gp_f32x4 *>(ob + (size_t)l * P + p);
+        if (NT) __builtin_nontemporal_store(v, o);
+        else *o = v;
       }
     }
+    ii = inext;
   }
 }
 
@@ -248,16 +260,47 @@ extern "C" void group_points_kernel_wrapper(int b, int c, int n, int npoints, in
                    ((reinterpret_cast<uintptr_t>(idx) & 15) == 0);
   static int use_lds = -1;
   if (use_lds < 0) { const char *e = getenv("PWCLO_GROUP_LDS"); use_lds = e ? atoi(e) : 1; }
-  if (vec && use_lds && n <= GP_LDS_MAXN && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
-    const int lds_bytes = GP_CH_PER_BLOCK * n * 4;
-    static bool attr_set = false;
-    if (lds_bytes > 64 * 1024 && !attr_set) {
-      (void)hipFuncSetAttribute((const void *)group_points_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GP_CH_PER_BLOCK * GP_LDS_MAXN * 4);
-      attr_set = true;
+  // rows of one channel slice in LDS: min(C, 8) x n floats, at most 128 KiB (8 x 4096, or e.g. the 3 coordinate rows of an
+  // 8192-point cloud)
+  const long long lds_need = (long long)min(c, GP_CH_PER_BLOCK) * n * 4;
+  if (vec && use_lds && lds_need <= (long long)GP_CH_PER_BLOCK * GP_LDS_MAXN * 4 && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
+    const int lds_bytes = (int)lds_need;
+    // Workgroup shape: 1024 threads (16 waves: one workgroup saturates a CU's store path) when the slices alone give every
+    // CU a workgroup, 256 threads otherwise; positions are split over just enough workgroups to put ~2 per CU (LDS
+    // permitting), so a channel slice's rows are staged once or twice, not once per 4096 positions (round 3: the
+    // 4096-position chunks re-staged the rows 4x at the largest shape and left the kernel at 0.60 of the HBM roof).
+    static int t_env = -1, tgt_env = -1, nt_env = -1;
+    if (t_env < 0) { const char *e = getenv("PWCLO_GP_THREADS"); t_env = e ? atoi(e) : 0; }
+    if (tgt_env < 0) { const char *e = getenv("PWCLO_GP_TARGET"); tgt_env = e ? atoi(e) : 0; }
+    if (nt_env < 0) { const char *e = getenv("PWCLO_GP_NT"); nt_env = e ? atoi(e) : 1; }
+    const long long slices = (long long)b * gy;
+    int T = t_env ? t_env : 1024;
+    // measured (profiles/r03: tools/gp_sweep.sh): two workgroups per CU pay while a slice's rows are <= 32 KiB; with 64 KiB
+    // rows a second staging per slice costs more than the overlap gives
+    const int target = tgt_env ? tgt_env : (lds_bytes < 64 * 1024 ? 512 : 256);
+    int gx = (int)max(1LL, (target + slices - 1) / slices);
+    const int max_gx = ceil_div(P, T * 4);
+    if (gx > max_gx) gx = max_gx;
+    const int per_wg = ceil_div(ceil_div(P, gx), T * 4) * T * 4;
+    gx = ceil_div(P, per_wg);
+#define GP_LAUNCH(TT, NTT)                                                                                      \
+    {                                                                                                           \
+      static bool attr_set = false;                                                                             \
+      if (lds_bytes > 64 * 1024 && !attr_set) {                                                                 \
+        (void)hipFuncSetAttribute((const void *)group_points_lds_kernel<TT, NTT>,                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, GP_CH_PER_BLOCK * GP_LDS_MAXN * 4); \
+        attr_set = true;                                                                                        \
+      }                                                                                                         \
+      hipLaunchKernelGGL((group_points_lds_kernel<TT, NTT>), dim3(gx, gy, b), dim3(TT), lds_bytes,              \
+                         current_stream(), c, n, P, per_wg, points, idx, out);                                  \
     }
-    hipLaunchKernelGGL(group_points_lds_kernel, dim3(ceil_div(P, GP_CHUNK), gy, b), dim3(GP_THREADS), lds_bytes,
-                       current_stream(), c, n, P, points, idx, out);
+    if (T == 1024 && nt_env) GP_LAUNCH(1024, true)
+    else if (T == 1024) GP_LAUNCH(1024, false)
+    else if (T == 512 && nt_env) GP_LAUNCH(512, true)
+    else if (T == 512) GP_LAUNCH(512, false)
+    else if (nt_env) GP_LAUNCH(256, true)
+    else GP_LAUNCH(256, false)
+#undef GP_LAUNCH
     check_launch("group_points");
     return;
   }
