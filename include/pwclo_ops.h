@@ -288,6 +288,16 @@ void pose_head_fused_kernel_wrapper(int b, int n, const float *emb, const float 
                                     const float *q_prev, const float *t_prev, float *q_out,
                                     float *t_out, float *pose_row, int row_stride);
 
+/* The same, followed in the same launch by the next (finer) level's quat_warp_pm(warp_src (b,warp_n,3), q_out, t_out) ->
+ * warp_out: bit-identical to the two separate launches (PW/pose_warp_refinement.py:104-106 is the first thing the next
+ * level does with this pose). */
+void pose_head_warp_fused_kernel_wrapper(int b, int n, const float *emb, const float *mask,
+                                         const float *w_qt, const float *b_qt, const float *w_q,
+                                         const float *b_q, const float *w_t, const float *b_t,
+                                         const float *q_prev, const float *t_prev, float *q_out,
+                                         float *t_out, float *pose_row, int row_stride, int warp_n,
+                                         const float *warp_src, float *warp_out);
+
 /* Deterministic (atomics-free) form of group_points_grad / gather_points_grad (nsample = 1): the caller
  * supplies the inverse of idx per cloud -- perm (b, npoints*nsample) i32 = positions p sorted by idx[b,p]
  * (stable: ascending p inside a source point), seg (b, n+1) i32 = segment starts -- and every

@@ -79,6 +79,7 @@ SIGNATURES = {
     "cv_fused_b_kernel_wrapper": ([_i] * 4 + [_F] * 6, None),
     "masked_pool_kernel_wrapper": ([_i, _i, _F, _F, _F], None),
     "pose_head_fused_kernel_wrapper": ([_i, _i] + [_F] * 13 + [_i], None),
+    "pose_head_warp_fused_kernel_wrapper": ([_i, _i] + [_F] * 13 + [_i, _i, _F, _F], None),
     "linear_jobs_kernel_wrapper": ([_i] + [ctypes.POINTER(ctypes.c_int)] * 3 + [ctypes.POINTER(ctypes.c_void_p)] * 3
                                    + [ctypes.POINTER(ctypes.c_int)], None),
     "sa_fused_h_kernel_wrapper": ([_i] * 7 + [_F] * 6 + [_i] * 3, None),

@@ -828,16 +828,20 @@ extern "C" void upconv_post_fused_h_kernel_wrapper(int njobs, int b, int n, int 
                {packed_post[0], packed_post[njobs - 1]}, {out[0], out[njobs - 1]}, b, n, s, k};
   const long long t16 = (long long)b * ((s + 15) / 16);
   const int lds = 4 * (layer_floats(1, 8) + layer_floats(8, 4) + layer_floats(4 + nb2, 4));
-  // 16-wave workgroups when every wave slot of the chip gets a tile, 8-wave ones (twice the workgroups) below that
-  const bool wide = t16 * njobs >= 4096;
-  const int W = wide ? 16 : 8;
+  // 16-wave workgroups when every wave slot of the chip gets a tile, 8-wave ones (twice the workgroups) below that, 4-wave
+  // ones at a coarse level (a few hundred tiles: spread them over as many CUs as possible)
+  const long long tiles = t16 * njobs;
+  const int W = tiles >= 4096 ? 16 : tiles >= 2048 ? 8 : 4;
   long long gx = (t16 + W - 1) / W;
-  const long long cap = (wide ? 512 : 1024) / njobs;
+  const long long cap = (W == 16 ? 512 : W == 8 ? 1024 : 2048) / njobs;
   if (gx > cap) gx = cap;
 #define UPP_CASE(NB2)                                                                                         \
   if (nb2 == NB2) {                                                                                           \
-    static bool attr16 = false, attr8 = false;                                                                \
-    if (wide) {                                                                                               \
+    static bool attr16 = false, attr8 = false, attr4 = false;                                                 \
+    if (W == 4) {                                                                                             \
+      if (!attr4) { (void)hipFuncSetAttribute((const void *)upconv_lane_post_kernel<NB2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr4 = true; } \
+      hipLaunchKernelGGL((upconv_lane_post_kernel<NB2, 4>), dim3((unsigned)gx, njobs), dim3(4 * 64), lds, current_stream(), a); \
+    } else if (W == 16) {                                                                                     \
       if (!attr16) { (void)hipFuncSetAttribute((const void *)upconv_lane_post_kernel<NB2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr16 = true; } \
       hipLaunchKernelGGL((upconv_lane_post_kernel<NB2, 16>), dim3((unsigned)gx, njobs), dim3(16 * 64), lds, current_stream(), a); \
     } else {                                                                                                  \

@@ -615,6 +615,12 @@ struct PoseHeadArgs {
   float *q_out, *t_out;             // (B,4), (B,3)
   float *pose_row;                  // (B, row_stride) base of this level's row; 7 floats written
   int n, row_stride;
+  // optional (round 3): the NEXT level's first step, warp(xyz, q, t) of PW/pose_warp_refinement.py:104-106 on the
+  // finer cloud with the pose this launch has just composed -- the same expressions as csrc/warp.hip quat_warp_kernel
+  // (bit-identical output), one launch fewer per level
+  const float *warp_src;            // (B, warp_n, 3) point-major, or nullptr
+  float *warp_out;                  // (B, warp_n, 3)
+  int warp_n;
 };
 
 __device__ __forceinline__ void quat_mul(const float *a, const float *b, float *r) {
@@ -634,6 +640,7 @@ __global__ __launch_bounds__(64 * MP_PARTS) void pose_head_kernel(PoseHeadArgs a
   __shared__ float pooled[64];
   __shared__ float big[256];
   __shared__ float qt[8];
+  __shared__ float pose_s[8];
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6, b = blockIdx.x, n = a.n;
   const int c4 = 4 * (c & 15), sub = c >> 4, slot = 4 * part + sub;
   const float *e = a.emb + (size_t)b * n * 64 + c4, *m = a.mask + (size_t)b * n * 64 + c4;
@@ -705,12 +712,32 @@ __global__ __launch_bounds__(64 * MP_PARTS) void pose_head_kernel(PoseHeadArgs a
       for (int i = 0; i < 4; ++i) q[i] = qd[i];
       for (int i = 0; i < 3; ++i) t[i] = td[i];
     }
-    for (int i = 0; i < 4; ++i) a.q_out[b * 4 + i] = q[i];
-    for (int i = 0; i < 3; ++i) a.t_out[b * 3 + i] = t[i];
+    for (int i = 0; i < 4; ++i) { a.q_out[b * 4 + i] = q[i]; pose_s[i] = q[i]; }
+    for (int i = 0; i < 3; ++i) { a.t_out[b * 3 + i] = t[i]; pose_s[4 + i] = t[i]; }
     const float nn = sqrtf((((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]) + 1e-10f) + 1e-10f;
     float *row = a.pose_row + (size_t)b * a.row_stride;
     row[0] = t[0]; row[1] = t[1]; row[2] = t[2];
     for (int i = 0; i < 4; ++i) row[3 + i] = q[i] / nn;
+  }
+  if (a.warp_src != nullptr) {                   // workgroup-uniform
+    __syncthreads();
+    const float qw = pose_s[0], qx = pose_s[1], qy = pose_s[2], qz = pose_s[3];
+    const float tx = pose_s[4], ty = pose_s[5], tz = pose_s[6];
+    // inv_q (PWCLO_utils.py:31-39): conj(q) / (sum(q*q) + 1e-10)
+    const float q2 = (((qw * qw + qx * qx) + qy * qy) + qz * qz) + 1e-10f;
+    const float iw = qw / q2, ix = (qx * -1.0f) / q2, iy = (qy * -1.0f) / q2, iz = (qz * -1.0f) / q2;
+    const float *src = a.warp_src + (size_t)b * 3 * a.warp_n;
+    float *dst = a.warp_out + (size_t)b * 3 * a.warp_n;
+    for (int j = threadIdx.x; j < a.warp_n; j += 64 * MP_PARTS) {
+      const float pq[4] = {qw, qx, qy, qz}, pp[4] = {0.0f, src[3 * j], src[3 * j + 1], src[3 * j + 2]};
+      const float pi[4] = {iw, ix, iy, iz};
+      float r1[4], r2[4];
+      quat_mul(pq, pp, r1);                     // same left-to-right component sums as warp.hip: hamilton()
+      quat_mul(r1, pi, r2);
+      dst[3 * j] = r2[1] + tx;
+      dst[3 * j + 1] = r2[2] + ty;
+      dst[3 * j + 2] = r2[3] + tz;
+    }
   }
 }
 
@@ -909,7 +936,22 @@ extern "C" void pose_head_fused_kernel_wrapper(int b, int n, const float *emb, c
                                                const float *q_prev, const float *t_prev, float *q_out,
                                                float *t_out, float *pose_row, int row_stride) {
   if (b <= 0 || n <= 0) return;
-  PoseHeadArgs a{emb, mask, w_qt, b_qt, w_q, b_q, w_t, b_t, q_prev, t_prev, q_out, t_out, pose_row, n, row_stride};
+  PoseHeadArgs a{emb, mask, w_qt, b_qt, w_q, b_q, w_t, b_t, q_prev, t_prev, q_out, t_out, pose_row, n, row_stride,
+                 nullptr, nullptr, 0};
   hipLaunchKernelGGL(pose_head_kernel, dim3(b), dim3(64 * MP_PARTS), 0, current_stream(), a);
   check_launch("pose_head_fused");
+}
+
+extern "C" void pose_head_warp_fused_kernel_wrapper(int b, int n, const float *emb, const float *mask,
+                                                    const float *w_qt, const float *b_qt, const float *w_q,
+                                                    const float *b_q, const float *w_t, const float *b_t,
+                                                    const float *q_prev, const float *t_prev, float *q_out,
+                                                    float *t_out, float *pose_row, int row_stride, int warp_n,
+                                                    const float *warp_src, float *warp_out) {
+  if (b <= 0 || n <= 0) return;
+  PWCLO_REQUIRE(warp_n > 0 && warp_src != nullptr && warp_out != nullptr, "pose_head_warp_fused: needs a cloud to warp (n=%d)", warp_n);
+  PoseHeadArgs a{emb, mask, w_qt, b_qt, w_q, b_q, w_t, b_t, q_prev, t_prev, q_out, t_out, pose_row, n, row_stride,
+                 warp_src, warp_out, warp_n};
+  hipLaunchKernelGGL(pose_head_kernel, dim3(b), dim3(64 * MP_PARTS), 0, current_stream(), a);
+  check_launch("pose_head_warp_fused");
 }

@@ -435,17 +435,23 @@ class FusedPoseHead:
         self.w_q, self.b_q = g(module.conv1d_q)
         self.w_t, self.b_t = g(module.conv1d_t)
 
-    def __call__(self, emb, mask, pose_params, level_row, q_prev=None, t_prev=None):
+    def __call__(self, emb, mask, pose_params, level_row, q_prev=None, t_prev=None, warp_next=None):
         """emb, mask (B,N,64); pose_params (B,4,7) output buffer, `level_row` = which row to fill;
-        q_prev (B,4) / t_prev (B,3) = coarse pose to refine (None at level 4).  -> q (B,4), t (B,3)."""
+        q_prev (B,4) / t_prev (B,3) = coarse pose to refine (None at level 4).  -> q (B,4), t (B,3).
+        ``warp_next`` (B,M,3): also returns quat_warp_pm(warp_next, q, t), computed by the same launch."""
         B, N, _ = emb.shape
         q = torch.empty((B, 4), dtype=torch.float32, device=emb.device)
         t = torch.empty((B, 3), dtype=torch.float32, device=emb.device)
         row = pose_params.data_ptr() + 4 * 7 * level_row
-        _lib.call("pose_head_fused_kernel_wrapper", emb.device, B, N, _p(emb), _p(mask), _p(self.w_qt),
-                  _p(self.b_qt), _p(self.w_q), _p(self.b_q), _p(self.w_t), _p(self.b_t), _p(q_prev),
-                  _p(t_prev), _p(q), _p(t), row, 28)
-        return q, t
+        args = (B, N, _p(emb), _p(mask), _p(self.w_qt), _p(self.b_qt), _p(self.w_q), _p(self.b_q), _p(self.w_t),
+                _p(self.b_t), _p(q_prev), _p(t_prev), _p(q), _p(t), row, 28)
+        if warp_next is None:
+            _lib.call("pose_head_fused_kernel_wrapper", emb.device, *args)
+            return q, t
+        warp_next = warp_next.contiguous()
+        warped = torch.empty_like(warp_next)
+        _lib.call("pose_head_warp_fused_kernel_wrapper", emb.device, *args, warp_next.shape[1], _p(warp_next), _p(warped))
+        return q, t, warped
 
 
 # ---- hoisted first layers (csrc/fused_hoisted.hip) ------------------------------------------------------
@@ -628,7 +634,7 @@ def upconv_post_supported(ups, B, S):
     """The one-launch form (csrc/fused_hoisted.hip: upconv_lane_post_kernel) exists for fp32 tiles and pays once the
     jobs' 16-query tiles fill the chip's wave slots at least once (refinement levels 2 and 1 at batch 32)."""
     return (os.environ.get("PWCLO_UP_POST", "1") != "0" and all(u.wfmt == WFMT_F32 for u in ups)
-            and len(ups) * B * ((S + 15) // 16) >= 4096)
+            and len(ups) * B * ((S + 15) // 16) >= int(os.environ.get("PWCLO_UP_POST_MIN", "512")))
 
 
 def run_upconv_post(ups, xyz2, xyz1, feat2, pres, idx):
@@ -641,7 +647,8 @@ def run_upconv_post(ups, xyz2, xyz1, feat2, pres, idx):
     c2 = feat2.shape[2]
     outs = [torch.empty((B, S, 64), dtype=torch.float32, device=xyz2.device) for _ in ups]
     pa = lambda v: (ctypes.c_void_p * n)(*v)
-    _lib.annotate(family="mlp", kernel="upconv_lane_post_kernel<%d, %d>" % (c2 // 16, 16 if n * B * ((S + 15) // 16) >= 4096 else 8),
+    tiles = n * B * ((S + 15) // 16)
+    _lib.annotate(family="mlp", kernel="upconv_lane_post_kernel<%d, %d>" % (c2 // 16, 16 if tiles >= 4096 else 8 if tiles >= 2048 else 4),
                   flops=sum(2.0 * B * S * (K * (u.macs - 64 * 128) + u.post.macs) for u in ups),
                   bytes=4.0 * n * B * (S * K * (1 + 3 + 128) + 3 * S + S * c2 + 64 * S))
     _lib.call("upconv_post_fused_h_kernel_wrapper", xyz2.device, n, B, N, S, K, c2, _p(xyz2), _p(xyz1), _p(idx), _p(feat2),
@@ -845,7 +852,10 @@ class FusedPWCLONet:
             self.pwr.append(d)
 
     def _refine(self, br, d, row, pose, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev,
-                taps=None, tap=""):
+                taps=None, tap="", warped=None, warp_next=None):
+        """``warped``: quat_warp_pm(x1, q_prev, t_prev) when the previous level's pose head already produced it;
+        ``warp_next``: the next (finer) level's cloud, warped by this level's head with the pose it composes (returned as a
+        fifth value)."""
         idx_up = br.hold(knn(8, x1_prev, x1))
         if taps is not None:
             taps[tap + ".up.idx"] = idx_up
@@ -861,7 +871,8 @@ class FusedPWCLONet:
                 up_feat = br.hold(d["up_f"](x1, x1_prev, f1, pre_f if self.hoist else emb_prev, idx_up))
             with br.fork(2):        # ... and of the mask are independent of the warp -> cost-volume chain
                 up_mask = br.hold(d["up_m"](x1, x1_prev, f1, pre_m if self.hoist else mask_prev, idx_up))
-        warped = br.hold(quat_warp_pm(x1, q_prev, t_prev))
+        if warped is None:
+            warped = br.hold(quat_warp_pm(x1, q_prev, t_prev))
         if taps is not None:
             taps[tap + ".warped"] = warped
         resid = br.hold(d["cv"](warped, x2, u, v, u2, taps=taps, tap=tap + ".cv") if self.hoist else
@@ -871,6 +882,9 @@ class FusedPWCLONet:
             br.join(2)
         emb = d["pred_f"](f1, resid, up_feat)
         mask = up_mask if d["last"] else d["pred_m"](up_mask, emb, f1)
+        if warp_next is not None:
+            q, t, w_next = br.hold(*d["head"](emb, mask, pose, row, q_prev, t_prev, warp_next=warp_next))
+            return q, t, emb, mask, w_next
         q, t = d["head"](emb, mask, pose, row, q_prev, t_prev)
         return q, t, emb, mask
 
@@ -967,14 +981,23 @@ class FusedPWCLONet:
             taps["ffe.knn_idx"] = idx_ffe
         mask4 = self.l4_pred(f14, emb4)
         pose = torch.empty((B, 4, 7), dtype=torch.float32, device=x.device)   # rows = levels 1..4
-        q4, t4 = self.l4_head(emb4, mask4, pose, 3)
-
-        q3, t3, emb3, mask3 = self._refine(br, self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4,
-                                           taps, "pwr3")
-        q2, t2, emb2, mask2 = self._refine(br, self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3,
-                                           taps, "pwr2")
-        q1, t1, emb1, mask1 = self._refine(br, self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2,
-                                           taps, "pwr1")
+        if os.environ.get("PWCLO_HEAD_WARP", "1") != "0":
+            # every pose head also warps the next finer cloud with the pose it has just composed (one launch fewer per level)
+            q4, t4, w3 = br.hold(*self.l4_head(emb4, mask4, pose, 3, warp_next=x13))
+            q3, t3, emb3, mask3, w2 = self._refine(br, self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4,
+                                                   taps, "pwr3", warped=w3, warp_next=x12)
+            q2, t2, emb2, mask2, w1 = self._refine(br, self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3,
+                                                   taps, "pwr2", warped=w2, warp_next=x11)
+            q1, t1, emb1, mask1 = self._refine(br, self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2,
+                                               taps, "pwr1", warped=w1)
+        else:
+            q4, t4 = self.l4_head(emb4, mask4, pose, 3)
+            q3, t3, emb3, mask3 = self._refine(br, self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4,
+                                               taps, "pwr3")
+            q2, t2, emb2, mask2 = self._refine(br, self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3,
+                                               taps, "pwr2")
+            q1, t1, emb1, mask1 = self._refine(br, self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2,
+                                               taps, "pwr1")
         if return_intermediates:
             return pose, dict(x11=x11, f11=f11, f13=f13, flow=flow, emb4=emb4, mask4=mask4, emb3=emb3,
                               mask3=mask3, emb2=emb2, mask2=mask2, emb1=emb1, mask1=mask1, q=(q1, q2, q3, q4),

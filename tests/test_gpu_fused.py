@@ -196,6 +196,12 @@ def test_fused_pointwise_and_pose_head(cuda):
     close(t, rt.squeeze(2))
     close(pose[:, 3, :3], rt.squeeze(2))
     close(pose[:, 3, 3:], rq.squeeze(2))          # already unit: the row normalisation is a no-op
+    # the same launch can also warp the next level's cloud with the pose it composed: bit-identical to quat_warp_pm
+    nxt = cloud(21, 3, 777).to(cuda)
+    pose2 = torch.zeros(3, 4, 7, device=cuda)
+    q2, t2, warped = head(pm(emb).to(cuda), pm(mask).to(cuda), pose2, 3, warp_next=nxt)
+    assert torch.equal(q2, q) and torch.equal(t2, t) and torch.equal(pose2, pose)
+    assert torch.equal(warped, fused.quat_warp_pm(nxt, q, t))
     assert (pose[:, :3] == 0).all()
     # refinement level: composition with a coarse pose (pose_warp_refinement.py:139,148)
     qc = F.normalize(torch.randn(3, 4, generator=g), dim=1)
