@@ -75,7 +75,14 @@ __device__ __forceinline__ unsigned fps_bitrev(unsigned v, int bits) {
 constexpr int FPS_CHAIN_INTS = 12;    // [0] fallback flag, [1] number of events, [2..9] event iterations
 constexpr int FPS_CHAIN_MAXEV = 8;
 
-template <int T, int E, int I, bool LDS_TABLE>
+// XCHG (round 3, multi-wave kernels with the LDS table): the winner's coordinates travel WITH the exchange instead of
+// being looked up after it.  Every lane requests the coordinates of its own best candidate from the LDS table right after
+// the update loop -- the read's latency hides under the two wave reductions -- and the lane that wins its wave stores them
+// in the wave's slot of a double-buffered 8-entry table before the barrier; after the barrier the slot key and the eight
+// coordinate slots are read in ONE round trip and the winner's are picked with v_readlane (its wave follows from the key).
+// Removes the dependent table read (key -> index -> coordinates) from the head of the next iteration.  Same arithmetic,
+// same winner: bit-identical output (tests/test_gpu_ops.py FPS cases run both forms).
+template <int T, int E, int I, bool LDS_TABLE, bool XCHG = false>
 __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int log2bs,
                                                     const float *__restrict__ dataset,
                                                     int *__restrict__ idxs,
@@ -85,6 +92,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
                                                     const int *__restrict__ done = nullptr) {
   TraceScope trace_scope_(TK_FPS);
   constexpr int PPT = I << E;
+  constexpr int NW_ = T / 64;
   if (done != nullptr && done[blockIdx.x] != 0) return;   // this cloud was sampled by fps_slab_kernel (workgroup-uniform)
   if (prefix_in != nullptr && prefix_in[blockIdx.x * FPS_CHAIN_INTS] == 0) {       // workgroup-uniform
     const int *rec = prefix_in + blockIdx.x * FPS_CHAIN_INTS;
@@ -161,6 +169,13 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
     for (int i = tid; i < tie_iters + 2; i += T) { cstat[i] = 0; cvals[i] = 0u; }
   __syncthreads();
 
+  constexpr bool XC = XCHG && LDS_TABLE && NW_ > 1;
+  __shared__ float4 wxyz[2][XC ? NW_ : 1];      // [iteration parity][wave]: coordinates of each wave's local winner
+  float nx1 = 0.f, ny1 = 0.f, nz1 = 0.f;        // XC: coordinates of the current sample, carried over from the exchange
+  if (XC) {
+    const float4 p0 = table[0];
+    nx1 = p0.x; ny1 = p0.y; nz1 = p0.z;
+  }
   int old = 0;
   // One iteration; TRACK additionally records whether the arg-max was unique.  Two instantiations run
   // back to back (iterations < tie_iters, then the rest) rather than one loop with a branch inside:
@@ -168,7 +183,9 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
   auto iteration = [&](auto track_tag, int it) {
     constexpr bool TRACK = decltype(track_tag)::value;
     float x1, y1, z1;
-    if (LDS_TABLE) {
+    if (XC) {
+      x1 = nx1; y1 = ny1; z1 = nz1;
+    } else if (LDS_TABLE) {
       const float4 p = table[old];
       x1 = p.x; y1 = p.y; z1 = p.z;
     } else {
@@ -192,6 +209,12 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
       bestj = better ? j : bestj;
       best = better ? d2 : best;
     }
+    float4 mycand = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (XC) {   // coordinates of this lane's own candidate: requested now, needed after the wave reductions
+      const int u = E == 0 ? 0 : (int)(__brev((unsigned)(bestj / I)) >> (32 - (E == 0 ? 1 : E)));
+      const int kc = tid + T * u + kstride * (bestj % I);
+      mycand = table[kc < n ? kc : 0];
+    }
     const bool lane_tie = TRACK && best >= 0 && best2 == best;
     // 0 = no candidate; otherwise bits+1 so that a legitimate distance of +0.0 stays distinct
     const unsigned mine = best < 0 ? 0u : (unsigned)best + 1u;
@@ -211,9 +234,25 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
     if (NW > 1) {
       unsigned long long *slot = slots + (it % 3);
       if (lane == 0) atomicMax(slot, key);
+      if (XC && holds && mypri == wpri) wxyz[it & 1][tid >> 6] = mycand;     // exactly one lane per wave with a candidate
       __syncthreads();
       key = *slot;
+      float4 all = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (XC) all = wxyz[it & 1][lane & (NW - 1)];                           // same round trip as the key
       if (tid == 0) slots[(it + 2) % 3] = 0ull;
+      if (XC) {
+        if (key == 0ull) {                       // no candidate anywhere: the reference falls back to index 0
+          const float4 p0 = table[0];
+          nx1 = p0.x; ny1 = p0.y; nz1 = p0.z;
+        } else {
+          const unsigned pw = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+          const int kw = (int)fps_bitrev(pw >> PRI_SHIFT, log2bs) + bs * (int)(pw & ((1u << PRI_SHIFT) - 1u));
+          const int wsel = __builtin_amdgcn_readfirstlane((kw & (T - 1)) >> 6);   // the wave that owns point kw
+          nx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(all.x), wsel));
+          ny1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(all.y), wsel));
+          nz1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(all.z), wsel));
+        }
+      }
       // another wave reached the same maximal distance with a different point
       if (TRACK) tie = tie || (wmax != 0u && wmax == (unsigned)(key >> 32) && wkey != key);
     }
@@ -239,6 +278,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
     oxyz[(m - 1) * 3 + 1] = pts[old * 3 + 1];
     oxyz[(m - 1) * 3 + 2] = pts[old * 3 + 2];
   }
+  (void)nx1; (void)ny1; (void)nz1;
   if (tie_out != nullptr) {
     // Judge the log: a tie at iteration i < tie_iters is a simple event iff iteration i+1 had no tie
     // and won with the same value (the other tied point, alone at V); anything else -> fallback.
@@ -851,7 +891,18 @@ static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float 
   hipStream_t st = current_stream();
   static int use_table = -1;
   if (use_table < 0) { const char *e = getenv("PWCLO_FPS_TABLE"); use_table = e ? atoi(e) : 1; }
-  if (table_bytes <= 160 * 1024 && (use_table || table_bytes <= 64 * 1024)) {
+  static int use_xchg = -1;
+  if (use_xchg < 0) { const char *e = getenv("PWCLO_FPS_XCHG"); use_xchg = e ? atoi(e) : 0; }   // measured SLOWER (profiles/r03/r03_fps_exchange_variant.txt): opt-in
+  if (table_bytes + 512 <= 160 * 1024 && T > 64 && use_xchg && (use_table || table_bytes <= 64 * 1024)) {
+    auto kern = fps_reg_kernel<T, E, I, true, true>;       // coordinates travel with the exchange
+    static bool big_lds_enabled = false;
+    if (table_bytes > 60 * 1024 && !big_lds_enabled) {
+      (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+      big_lds_enabled = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(b), dim3(T), table_bytes, st, n, m, bs, log2bs, dataset, idxs, new_xyz, tie_out,
+                       tie_iters, prefix_in, t_done_flags);
+  } else if (table_bytes <= 160 * 1024 && (use_table || table_bytes <= 64 * 1024)) {
     auto kern = fps_reg_kernel<T, E, I, true>;
     static bool big_lds_enabled = false;  // per instantiation; raises the 64 KiB dynamic-LDS default
     if (table_bytes > 64 * 1024 && !big_lds_enabled) {
