@@ -156,6 +156,11 @@ int knn_point_slabs(int n);
 void knn_build_kernel_wrapper(int b, int n, const float *xyz, void *workspace, int *slab_tab);
 void knn_point_prebuilt_kernel_wrapper(int b, int n, int s, int nsample, const float *new_xyz, int *idx, float *dist,
                                        void *workspace);
+/* The same search on clouds [first_cloud, first_cloud + b) of a structure that knn_build / knn_point_ws built for
+ * built_b >= first_cloud + b clouds of n points (the pyramid builds both frames' clouds as one batch; a refinement level
+ * searches one frame's half of it without rebuilding).  new_xyz (b,s,3), idx (b,s,nsample). */
+void knn_point_prebuilt_slice_kernel_wrapper(int b, int n, int s, int nsample, const float *new_xyz, int *idx,
+                                             float *dist, void *workspace, int first_cloud, int built_b);
 /* Large clouds (n > 24576) presented in a spatially coherent order: sorted (b,n,3) = dataset gathered by perm (b,n),
  * perm[p] = original index of sorted position p; inside every block of 1024 consecutive positions the positions are
  * ordered by ascending sampling priority (bitrev(k mod bs) << 23 | k div bs of the original index k).  A wave of the

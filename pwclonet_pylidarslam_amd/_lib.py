@@ -44,6 +44,7 @@ SIGNATURES = {
     "knn_point_slabs": ([_i], _i),
     "knn_build_kernel_wrapper": ([_i, _i, _F, _F, _F], None),
     "knn_point_prebuilt_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
+    "knn_point_prebuilt_slice_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F, _i, _i], None),
     "furthest_point_sampling_sorted_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F, _F, _F], None),
     "furthest_point_sampling_slab_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F, _i, _F, _F, _F], None),
     "quat_warp_kernel_wrapper": ([_i, _i, _F, _F, _F, _F], None),

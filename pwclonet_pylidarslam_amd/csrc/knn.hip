@@ -816,12 +816,16 @@ static bool knn_build_launch(int b, int n, const float *xyz, void *workspace, in
   return check_launch("knn_point(build)");
 }
 
+// `first_cloud` / `built_b`: the structure in `workspace` was built for `built_b` clouds and this search covers the `b`
+// clouds starting at `first_cloud` of them (the siamese pyramid builds both frames' clouds in one batch; the refinement
+// levels search one frame's half -- round 3).  The defaults describe a structure built for exactly these b clouds.
 static void knn_search_launch(int b, int n, int s, int nsample, const float *new_xyz, int *idx, float *dist,
-                              void *workspace) {
+                              void *workspace, int first_cloud = 0, int built_b = -1) {
   const int nslab = knn_slabs(n);
   const int nblk = (n + 63) / 64 + nslab;
-  float4 *rows = reinterpret_cast<float4 *>(workspace);
-  float4 *boxes = rows + (size_t)b * nblk * 64;
+  if (built_b < 0) built_b = b;
+  float4 *rows = reinterpret_cast<float4 *>(workspace) + (size_t)first_cloud * nblk * 64;
+  float4 *boxes = reinterpret_cast<float4 *>(workspace) + (size_t)built_b * nblk * 64 + (size_t)first_cloud * nblk * 2;
   // K <= 32: several queries per wave (knn_rows_kernel); PWCLO_KNN_ROWS=0 keeps one query per wave (A/B switch)
   static int use_rows = -1;
   if (use_rows < 0) { const char *e = getenv("PWCLO_KNN_ROWS"); use_rows = e ? atoi(e) : 1; }
@@ -879,6 +883,18 @@ extern "C" void knn_point_prebuilt_kernel_wrapper(int b, int n, int s, int nsamp
   PWCLO_REQUIRE(nsample >= 1 && nsample <= 64 && nsample <= n, "knn_point(prebuilt): nsample=%d invalid for n=%d", nsample, n);
   PWCLO_REQUIRE(b <= 65535, "knn_point(prebuilt): b=%d exceeds the grid limit", b);
   knn_search_launch(b, n, s, nsample, new_xyz, idx, dist, workspace);
+}
+
+extern "C" void knn_point_prebuilt_slice_kernel_wrapper(int b, int n, int s, int nsample, const float *new_xyz, int *idx,
+                                                        float *dist, void *workspace, int first_cloud, int built_b) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(workspace != nullptr && n >= 64 && n <= pwclo::KNN_MAX_SORT,
+                "knn_point(prebuilt slice): n=%d outside [64,%d] or no workspace", n, pwclo::KNN_MAX_SORT);
+  PWCLO_REQUIRE(nsample >= 1 && nsample <= 64 && nsample <= n, "knn_point(prebuilt slice): nsample=%d invalid for n=%d", nsample, n);
+  PWCLO_REQUIRE(first_cloud >= 0 && built_b >= 1 && first_cloud + b <= built_b && built_b <= 65535,
+                "knn_point(prebuilt slice): clouds [%d, %d) are not inside the %d the structure was built for", first_cloud,
+                first_cloud + b, built_b);
+  knn_search_launch(b, n, s, nsample, new_xyz, idx, dist, workspace, first_cloud, built_b);
 }
 
 extern "C" int knn_point_slabs(int n) { return knn_slabs(n); }

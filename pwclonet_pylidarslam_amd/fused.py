@@ -292,6 +292,35 @@ def knn(nsample, xyz, new_xyz):
     return _ext.knn_point(nsample, xyz, new_xyz)
 
 
+def knn_keep(nsample, xyz, new_xyz):
+    """``knn`` that also hands back the search structure it built for ``xyz`` (sorted rows + block boxes of all its
+    clouds), or None when the call used the exhaustive kernel: ``(idx, (workspace, clouds, n) | None)``."""
+    from .pointnet2_ops import _ext
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    ws_bytes = _lib.load().knn_point_workspace_bytes(B, N) if S >= _ext._KNN_MIN_S else 0
+    if ws_bytes <= 0:
+        return knn(nsample, xyz, new_xyz), None
+    idx = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=xyz.device)
+    _lib.annotate(family="knn", units=float(B) * S * N, bytes=4.0 * B * (3 * N + 3 * S + S * nsample))
+    _lib.call("knn_point_ws_kernel_wrapper", xyz.device, B, N, S, int(nsample), _p(xyz.contiguous()),
+              _p(new_xyz.contiguous()), _p(idx), 0, _p(ws))
+    return idx, (ws, B, N)
+
+
+def knn_on(struct, first_cloud, nsample, new_xyz):
+    """Search pass alone on clouds [first_cloud, first_cloud + B) of a structure ``knn_keep`` returned (B = new_xyz's
+    batch): the same lists as ``knn(nsample, those clouds, new_xyz)``, without sorting them again."""
+    ws, built_b, N = struct
+    B, S, _ = new_xyz.shape
+    idx = torch.empty((B, S, nsample), dtype=torch.int32, device=new_xyz.device)
+    _lib.annotate(family="knn", units=float(B) * S * N, bytes=4.0 * B * (3 * N + 3 * S + S * nsample))
+    _lib.call("knn_point_prebuilt_slice_kernel_wrapper", new_xyz.device, B, N, S, int(nsample), _p(new_xyz.contiguous()),
+              _p(idx), 0, _p(ws), int(first_cloud), int(built_b))
+    return idx
+
+
 # ---- point-wise MLP over concatenated sources ----------------------------------------------------------
 
 class FusedPointwise:
@@ -852,11 +881,13 @@ class FusedPWCLONet:
             self.pwr.append(d)
 
     def _refine(self, br, d, row, pose, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev,
-                taps=None, tap="", warped=None, warp_next=None):
+                taps=None, tap="", warped=None, warp_next=None, st_up=None, st_q=None):
         """``warped``: quat_warp_pm(x1, q_prev, t_prev) when the previous level's pose head already produced it;
         ``warp_next``: the next (finer) level's cloud, warped by this level's head with the pose it composes (returned as a
-        fifth value)."""
-        idx_up = br.hold(knn(8, x1_prev, x1))
+        fifth value).  ``st_up`` / ``st_q``: search structures (``knn_keep``) the pyramid built for the 2B clouds that
+        x1_prev (frame 1: clouds [0, B)) and x2 (frame 2: clouds [B, 2B)) belong to, or None."""
+        B = x1.shape[0]
+        idx_up = br.hold(knn_on(st_up, 0, 8, x1) if st_up is not None and x1.shape[1] >= 256 else knn(8, x1_prev, x1))
         if taps is not None:
             taps[tap + ".up.idx"] = idx_up
         if self.hoist:          # all per-point partial products of this level in one launch
@@ -875,7 +906,10 @@ class FusedPWCLONet:
             warped = br.hold(quat_warp_pm(x1, q_prev, t_prev))
         if taps is not None:
             taps[tap + ".warped"] = warped
-        resid = br.hold(d["cv"](warped, x2, u, v, u2, taps=taps, tap=tap + ".cv") if self.hoist else
+        idx_q = None
+        if self.hoist and st_q is not None and warped.shape[1] >= 256:
+            idx_q = br.hold(knn_on(st_q, B, d["cv"].nsample_q, warped))
+        resid = br.hold(d["cv"](warped, x2, u, v, u2, idx_q=idx_q, taps=taps, tap=tap + ".cv") if self.hoist else
                         d["cv"](warped, f1, x2, f2, taps=taps, tap=tap + ".cv"))
         br.join(1)
         if not one_launch:
@@ -948,6 +982,8 @@ class FusedPWCLONet:
         B, x, samples, ready, br = state["B"], state["x"], state["samples"], state["ready"], state["br"]
         f = None
         lv = []
+        reuse = os.environ.get("PWCLO_KNN_REUSE", "1") != "0"
+        built = {}                       # pyramid level -> search structure of its 2B clouds (knn_keep)
         # neighbour lists of every knn call (tests compare them with the oracle's); only when asked for
         taps = {} if return_intermediates else None
         for lvl, (fsa, (npoint, nsample)) in enumerate(zip(self.sa, self.sa_cfg)):
@@ -955,6 +991,14 @@ class FusedPWCLONet:
             new_x = samples[lvl]
             if lvl == 0 and state.get("ws0") is not None:     # the sampler already built this cloud's search structure
                 idx = br.hold(knn_prebuilt(nsample, x, new_x, state["ws0"]))
+            elif reuse:
+                # keep the structure built for this level's candidate clouds (both frames): the refinement levels search
+                # one frame's half of it again (set-upconv lists: frame 1; cost-volume lists: frame 2)
+                idx, st = knn_keep(nsample, x, new_x)
+                br.hold(idx)
+                if st is not None:
+                    built[lvl] = st              # structure of pyramid cloud `lvl` (0 = the input clouds)
+                    br.hold(st[0])
             else:
                 idx = br.hold(knn(nsample, x, new_x))
             if taps is not None:
@@ -985,19 +1029,19 @@ class FusedPWCLONet:
             # every pose head also warps the next finer cloud with the pose it has just composed (one launch fewer per level)
             q4, t4, w3 = br.hold(*self.l4_head(emb4, mask4, pose, 3, warp_next=x13))
             q3, t3, emb3, mask3, w2 = self._refine(br, self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4,
-                                                   taps, "pwr3", warped=w3, warp_next=x12)
+                                                   taps, "pwr3", warped=w3, warp_next=x12, st_up=built.get(4), st_q=built.get(3))
             q2, t2, emb2, mask2, w1 = self._refine(br, self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3,
-                                                   taps, "pwr2", warped=w2, warp_next=x11)
+                                                   taps, "pwr2", warped=w2, warp_next=x11, st_up=built.get(3), st_q=built.get(2))
             q1, t1, emb1, mask1 = self._refine(br, self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2,
-                                               taps, "pwr1", warped=w1)
+                                               taps, "pwr1", warped=w1, st_up=built.get(2), st_q=built.get(1))
         else:
             q4, t4 = self.l4_head(emb4, mask4, pose, 3)
             q3, t3, emb3, mask3 = self._refine(br, self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4,
-                                               taps, "pwr3")
+                                               taps, "pwr3", st_up=built.get(4), st_q=built.get(3))
             q2, t2, emb2, mask2 = self._refine(br, self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3,
-                                               taps, "pwr2")
+                                               taps, "pwr2", st_up=built.get(3), st_q=built.get(2))
             q1, t1, emb1, mask1 = self._refine(br, self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2,
-                                               taps, "pwr1")
+                                               taps, "pwr1", st_up=built.get(2), st_q=built.get(1))
         if return_intermediates:
             return pose, dict(x11=x11, f11=f11, f13=f13, flow=flow, emb4=emb4, mask4=mask4, emb3=emb3,
                               mask3=mask3, emb2=emb2, mask2=mask2, emb1=emb1, mask1=mask1, q=(q1, q2, q3, q4),

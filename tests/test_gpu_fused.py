@@ -177,6 +177,23 @@ def test_fused_cost_volume_first_aggregate_as_one_kernel(cuda, monkeypatch, c, s
     assert torch.equal(outs["merged+v2"], outs["separate"])
 
 
+@pytest.mark.parametrize("n,s,k", [(2048, 2048, 6), (1024, 2048, 8), (1024, 1000, 6), (300, 256, 8)])
+def test_knn_search_on_a_slice_of_a_kept_structure(cuda, n, s, k):
+    """fused.knn_keep / knn_on (csrc/knn.hip knn_point_prebuilt_slice): the structure built once for the pyramid's 2B clouds
+    serves the refinement levels' searches on one frame's half -- the same lists, bit for bit, as a fresh knn on those
+    clouds, and as the oracle's."""
+    B = 3
+    both = cloud(31, 2 * B, n).to(cuda)
+    q = cloud(32, B, s).to(cuda) * 0.9
+    idx_all, st = fused.knn_keep(16, both, both[:, :256].contiguous())
+    assert st is not None
+    for first in (0, B):
+        got = fused.knn_on(st, first, k, q)
+        assert torch.equal(got, fused.knn(k, both[first:first + B].contiguous(), q))
+    ref = O.knn_point_with_dist(k, both[B:].cpu().contiguous(), q.cpu())[1]
+    assert torch.equal(fused.knn_on(st, B, k, q).cpu(), ref)
+
+
 def test_fused_pointwise_and_pose_head(cuda):
     g = torch.Generator().manual_seed(9)
     for chans in ((64, 64, 64), (32, 64, 64), (16, 64, 64), (64, 64, 32), (128, 64)):
