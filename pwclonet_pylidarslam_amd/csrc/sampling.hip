@@ -322,13 +322,17 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
 // ~4 of 128 per iteration, ~9 during the first 200) and re-reduces their summaries; a wave with an empty mask reuses
 // its cached arg-max.  Priorities derive from the ORIGINAL index each sorted row carries, hence the same winner as
 // fps_reg_kernel for every input (tests: lattice clouds, zero padding, chain records, benchmark clouds bit for bit).
-template <int T, int I>
+// LDS_TABLE = false: the winner's coordinates come from the original cloud in global memory (L2-resident) instead of a
+// 16-byte-per-point LDS copy: the workgroup then needs ~8 KiB of LDS instead of 139 KiB, so that SEVERAL pruned chains
+// can share a CU (each uses well under half of its issue slots; round 3 experiment, tools/fps_pair_probe.py).
+template <int T, int I, bool LDS_TABLE = true>
 __global__ __launch_bounds__(T) void fps_slab_kernel(int n, int m, int bs, int log2bs, int nblk,
                                                      const float4 *__restrict__ rows_all,
                                                      const int *__restrict__ slab_tab,
                                                      int *__restrict__ idxs, float *__restrict__ new_xyz,
                                                      int *__restrict__ tie_out, int tie_iters,
-                                                     int *__restrict__ status, int dbg) {
+                                                     int *__restrict__ status, int dbg,
+                                                     const float *__restrict__ dataset = nullptr) {
   TraceScope trace_scope_(TK_FPS);
   constexpr int NW = T / 64;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -342,10 +346,11 @@ __global__ __launch_bounds__(T) void fps_slab_kernel(int n, int m, int bs, int l
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [3] rotating
-  float4 *table = reinterpret_cast<float4 *>(smem + FPS_SLOT_BYTES);         // [n], by ORIGINAL index
-  unsigned *cvals = reinterpret_cast<unsigned *>(smem + FPS_SLOT_BYTES + (size_t)n * 16);
+  float4 *table = reinterpret_cast<float4 *>(smem + FPS_SLOT_BYTES);         // [n], by ORIGINAL index (LDS_TABLE)
+  unsigned *cvals = reinterpret_cast<unsigned *>(smem + FPS_SLOT_BYTES + (LDS_TABLE ? (size_t)n * 16 : 0));
   int *cstat = reinterpret_cast<int *>(cvals + (tie_iters + 2));
   int *cmeta = reinterpret_cast<int *>(smem + 32);
+  const float *opts = LDS_TABLE ? nullptr : dataset + (size_t)blockIdx.x * n * 3;
 
   const float4 *rows = rows_all + (size_t)blockIdx.x * nblk * 64;
   int *out = idxs + (size_t)blockIdx.x * m;
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(T) void fps_slab_kernel(int n, int m, int bs, int l
         t0 = 1e10f;
         lx = hx = px; ly = hy = py; lz = hz = pz;
       }
-      table[k] = make_float4(px, py, pz, 0.f);
+      if (LDS_TABLE) table[k] = make_float4(px, py, pz, 0.f);
     }
     x[j] = px; y[j] = py; z[j] = pz; td[j] = __float_as_int(t0); pri[j] = pr;
     lx = wave_allreduce_f32(lx, [](float a, float b) { return fminf(a, b); });
@@ -411,8 +416,13 @@ __global__ __launch_bounds__(T) void fps_slab_kernel(int n, int m, int bs, int l
   int old = 0;
   auto iteration = [&](auto track_tag, int it) {
     constexpr bool TRACK = decltype(track_tag)::value;
-    const float4 p1 = table[old];
-    const float x1 = p1.x, y1 = p1.y, z1 = p1.z;
+    float x1, y1, z1;
+    if (LDS_TABLE) {
+      const float4 p1 = table[old];
+      x1 = p1.x; y1 = p1.y; z1 = p1.z;
+    } else {
+      x1 = opts[old * 3 + 0]; y1 = opts[old * 3 + 1]; z1 = opts[old * 3 + 2];
+    }
     if (oxyz && tid == 0) {
       oxyz[(it - 1) * 3 + 0] = x1; oxyz[(it - 1) * 3 + 1] = y1; oxyz[(it - 1) * 3 + 2] = z1;
     }
@@ -496,8 +506,12 @@ __global__ __launch_bounds__(T) void fps_slab_kernel(int n, int m, int bs, int l
   for (; it < tracked_end; ++it) iteration(std::true_type{}, it);
   for (; it < m; ++it) iteration(std::false_type{}, it);
   if (oxyz && tid == 0) {
-    const float4 p = table[old];
-    oxyz[(m - 1) * 3 + 0] = p.x; oxyz[(m - 1) * 3 + 1] = p.y; oxyz[(m - 1) * 3 + 2] = p.z;
+    if (LDS_TABLE) {
+      const float4 p = table[old];
+      oxyz[(m - 1) * 3 + 0] = p.x; oxyz[(m - 1) * 3 + 1] = p.y; oxyz[(m - 1) * 3 + 2] = p.z;
+    } else {
+      oxyz[(m - 1) * 3 + 0] = opts[old * 3 + 0]; oxyz[(m - 1) * 3 + 1] = opts[old * 3 + 1]; oxyz[(m - 1) * 3 + 2] = opts[old * 3 + 2];
+    }
   }
   if (tie_out != nullptr) {      // judge the log exactly as fps_reg_kernel does
     int *rec = tie_out + blockIdx.x * FPS_CHAIN_INTS;
@@ -1165,11 +1179,25 @@ extern "C" void furthest_point_sampling_slab_kernel_wrapper(int b, int n, int m,
   const size_t lds = FPS_SLOT_BYTES + (size_t)n * sizeof(float4) + chain_bytes;
   PWCLO_REQUIRE(knn_point_slabs(n) == 8 && n >= 4096 && n <= 8 * 18 * 64 && lds <= 160 * 1024,
                 "furthest_point_sampling(slab): n=%d is outside the slab sampler's range (8 slabs, LDS table)", n);
-  (void)dataset;                                          // every point comes from the sorted rows
   const int nblk = (n + 63) / 64 + 8;
   const int per = (n + 7) / 8;
   const char *dbg_e = getenv("PWCLO_FPS_SLAB_DBG");
   const int dbg = dbg_e ? atoi(dbg_e) : 0;
+  static int lds_table = -1;
+  if (lds_table < 0) { const char *e = getenv("PWCLO_FPS_SLAB_TABLE"); lds_table = e ? atoi(e) : 1; }
+  if (!lds_table) {        // winner coordinates from the original cloud in global memory: a few KiB of LDS per workgroup
+    const size_t small = FPS_SLOT_BYTES + chain_bytes;
+    if (per <= 16 * 64)
+      hipLaunchKernelGGL((fps_slab_kernel<512, 16, false>), dim3(b), dim3(512), small, current_stream(), n, m, bs, log2bs,
+                         nblk, reinterpret_cast<const float4 *>(knn_workspace), slab_tab, idxs, new_xyz, tie_out, tie_iters,
+                         status, dbg, dataset);
+    else
+      hipLaunchKernelGGL((fps_slab_kernel<512, 18, false>), dim3(b), dim3(512), small, current_stream(), n, m, bs, log2bs,
+                         nblk, reinterpret_cast<const float4 *>(knn_workspace), slab_tab, idxs, new_xyz, tie_out, tie_iters,
+                         status, dbg, dataset);
+    check_launch("furthest_point_sampling(slab)");
+    return;
+  }
   static bool big16 = false, big18 = false;
 #define SLAB_LAUNCH(II, FLAG)                                                                                   \
   {                                                                                                             \
@@ -1180,7 +1208,7 @@ extern "C" void furthest_point_sampling_slab_kernel_wrapper(int b, int n, int m,
     }                                                                                                           \
     hipLaunchKernelGGL(kern, dim3(b), dim3(512), lds, current_stream(), n, m, bs, log2bs, nblk,                 \
                        reinterpret_cast<const float4 *>(knn_workspace), slab_tab, idxs, new_xyz, tie_out,       \
-                       tie_iters, status, dbg);                                                                 \
+                       tie_iters, status, dbg, dataset);                                                        \
   }
   if (per <= 16 * 64) SLAB_LAUNCH(16, big16) else SLAB_LAUNCH(18, big18)
 #undef SLAB_LAUNCH
