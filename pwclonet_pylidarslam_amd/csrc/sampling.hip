@@ -82,8 +82,14 @@ constexpr int FPS_CHAIN_MAXEV = 8;
 // coordinate slots are read in ONE round trip and the winner's are picked with v_readlane (its wave follows from the key).
 // Removes the dependent table read (key -> index -> coordinates) from the head of the next iteration.  Same arithmetic,
 // same winner: bit-identical output (tests/test_gpu_ops.py FPS cases run both forms).
-template <int T, int E, int I, bool LDS_TABLE, bool XCHG = false>
-__global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int log2bs,
+// CPW = 2 (round 3, tools/fps_pair_probe.py): TWO clouds per workgroup, T threads each, every cloud's eight waves meeting
+// at their OWN barrier -- an LDS counter the waves add to and poll -- so that the two dependent chains run side by side on
+// one CU and fill each other's exchange stalls (one chain leaves a third of the CU's issue slots idle: co-resident chains
+// measured -17 % CU-time per cloud at two, -28 % at four per CU).  Needs the global winner lookup (LDS_TABLE = false: two
+// 131 KB tables do not fit) and neither `prefix_in` nor `done` (their early exits are per cloud).  Same arithmetic, same
+// winner: bit-identical output.
+template <int T, int E, int I, bool LDS_TABLE, bool XCHG = false, int CPW = 1>
+__global__ __launch_bounds__(T * CPW) void fps_reg_kernel(int n, int m, int bs, int log2bs,
                                                     const float *__restrict__ dataset,
                                                     int *__restrict__ idxs,
                                                     float *__restrict__ new_xyz,
@@ -93,8 +99,11 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
   TraceScope trace_scope_(TK_FPS);
   constexpr int PPT = I << E;
   constexpr int NW_ = T / 64;
-  if (done != nullptr && done[blockIdx.x] != 0) return;   // this cloud was sampled by fps_slab_kernel (workgroup-uniform)
-  if (prefix_in != nullptr && prefix_in[blockIdx.x * FPS_CHAIN_INTS] == 0) {       // workgroup-uniform
+  static_assert(CPW == 1 || (CPW == 2 && !LDS_TABLE && !XCHG), "two clouds per workgroup: global winner lookup only");
+  const int half = CPW == 1 ? 0 : (int)(threadIdx.x / T);          // which of the workgroup's clouds (wave-uniform)
+  const int cloud = (int)blockIdx.x * CPW + half;
+  if (CPW == 1 && done != nullptr && done[blockIdx.x] != 0) return;   // this cloud was sampled by fps_slab_kernel (workgroup-uniform)
+  if (CPW == 1 && prefix_in != nullptr && prefix_in[blockIdx.x * FPS_CHAIN_INTS] == 0) {       // workgroup-uniform
     const int *rec = prefix_in + blockIdx.x * FPS_CHAIN_INTS;
     const int nev = rec[1];
     const float *src = dataset + (size_t)blockIdx.x * n * 3;
@@ -121,7 +130,10 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
   // a sampler wave is one link of a long dependent chain: whenever it can issue, it should, ahead of
   // the throughput kernels of other in-flight batches that may share its SIMD
   __builtin_amdgcn_s_setprio(3);
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  // CPW == 2: each cloud has its own slot header + chain log, one after the other
+  unsigned char *smem = smem_all + (CPW == 1 ? 0 : (size_t)half * ((FPS_SLOT_BYTES + (size_t)(tie_out ? (tie_iters + 2) * 8 : 0) + 15) & ~(size_t)15));
+  unsigned *arrive = reinterpret_cast<unsigned *>(smem + 48);                // CPW == 2: this cloud's barrier counter
   unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [3] rotating
   float4 *table = reinterpret_cast<float4 *>(smem + FPS_SLOT_BYTES);         // [n] when LDS_TABLE
   // chain log (only when tie_out): winning value and tie status of iterations 0..tie_iters+1, judged
@@ -130,12 +142,12 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
   int *cstat = reinterpret_cast<int *>(cvals + (tie_iters + 2));
   int *cmeta = reinterpret_cast<int *>(smem + 32);                           // [0] events, [1] fallback (slot header)
 
-  const int tid = threadIdx.x;
+  const int tid = CPW == 1 ? (int)threadIdx.x : (int)(threadIdx.x % T);
   const int lane = tid & 63;
   constexpr int NW = T / 64;
-  const float *pts = dataset + (size_t)blockIdx.x * n * 3;
-  int *out = idxs + (size_t)blockIdx.x * m;
-  float *oxyz = new_xyz ? new_xyz + (size_t)blockIdx.x * m * 3 : nullptr;  // optional (b,m,3) samples
+  const float *pts = dataset + (size_t)cloud * n * 3;
+  int *out = idxs + (size_t)cloud * m;
+  float *oxyz = new_xyz ? new_xyz + (size_t)cloud * m * 3 : nullptr;  // optional (b,m,3) samples
   const int kstride = E == 0 ? T : bs;  // distance between consecutive points of one residue
 
   float x[PPT], y[PPT], z[PPT];
@@ -164,6 +176,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
     out[0] = 0;
     slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull;
     cmeta[0] = 0; cmeta[1] = 0;
+    if (CPW > 1) *arrive = 0u;
   }
   if (tie_out != nullptr)
     for (int i = tid; i < tie_iters + 2; i += T) { cstat[i] = 0; cvals[i] = 0u; }
@@ -235,7 +248,18 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
       unsigned long long *slot = slots + (it % 3);
       if (lane == 0) atomicMax(slot, key);
       if (XC && holds && mypri == wpri) wxyz[it & 1][tid >> 6] = mycand;     // exactly one lane per wave with a candidate
-      __syncthreads();
+      if (CPW == 1) {
+        __syncthreads();
+      } else {
+        // this cloud's own barrier: a wave's LDS operations execute in order, so once the counter shows 8 arrivals for
+        // this iteration all eight arg-max updates above are in the slot
+        if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned want = (unsigned)NW * (unsigned)it;
+        while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <
+               (int)want)
+          __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+      }
       key = *slot;
       float4 all = make_float4(0.f, 0.f, 0.f, 0.f);
       if (XC) all = wxyz[it & 1][lane & (NW - 1)];                           // same round trip as the key
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int bs, int lo
   if (tie_out != nullptr) {
     // Judge the log: a tie at iteration i < tie_iters is a simple event iff iteration i+1 had no tie
     // and won with the same value (the other tied point, alone at V); anything else -> fallback.
-    int *rec = tie_out + blockIdx.x * FPS_CHAIN_INTS;
+    int *rec = tie_out + cloud * FPS_CHAIN_INTS;
     const bool enough = m >= tie_iters + 2;                 // decisions tie_iters-1 and tie_iters both made
     __syncthreads();
     if (enough) {
@@ -905,6 +929,21 @@ static void launch_fps_reg(int b, int n, int m, int bs, int log2bs, const float 
   hipStream_t st = current_stream();
   static int use_table = -1;
   if (use_table < 0) { const char *e = getenv("PWCLO_FPS_TABLE"); use_table = e ? atoi(e) : 1; }
+  static int use_pair = -1;
+  if (use_pair < 0) { const char *e = getenv("PWCLO_FPS_PAIR"); use_pair = e ? atoi(e) : 0; }   // opt-in: -15 % CU-time per cloud but 1.7x the chain latency (profiles/r03)
+  if constexpr (T == 512 && E == 0 && I == 16) {
+    // two clouds per 1024-thread workgroup, each with its own LDS barrier (see the kernel): the pyramid's first level
+    if (use_pair && (b % 2) == 0 && prefix_in == nullptr && t_done_flags == nullptr) {
+      auto kern = fps_reg_kernel<512, 0, 16, false, false, 2>;
+      // a dynamic-LDS request of 72 KiB (the kernel uses ~17 of them): two such workgroups may share a CU, the MFMA
+      // workgroups of other in-flight batches (>= 40 KiB of weights each) may not move in beside the chains
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); attr = true; }
+      hipLaunchKernelGGL(kern, dim3(b / 2), dim3(1024), 72 * 1024, st, n, m, bs, log2bs, dataset, idxs, new_xyz, tie_out,
+                         tie_iters, prefix_in, t_done_flags);
+      return;
+    }
+  }
   static int use_xchg = -1;
   if (use_xchg < 0) { const char *e = getenv("PWCLO_FPS_XCHG"); use_xchg = e ? atoi(e) : 0; }   // measured SLOWER (profiles/r03/r03_fps_exchange_variant.txt): opt-in
   if (table_bytes + 512 <= 160 * 1024 && T > 64 && use_xchg && (use_table || table_bytes <= 64 * 1024)) {
