@@ -327,6 +327,8 @@ void kitti360_filter_kernel_wrapper(int n, float ground_z, float near, const flo
  * the caller: zero rows are never selected by furthest_point_sampling), counts (b) i32 = min(kept, cap). */
 void compact_frames_kernel_wrapper(int b, int n, int cap, const int *keep, const int *pos, const float *xyz,
                                    float *out, int *counts);
+/* The same compaction with the scan inside (no `pos` input): one workgroup per frame, ballot / popcount slots, stable. */
+void compact_frames_scan_kernel_wrapper(int b, int n, int cap, const int *keep, const float *xyz, float *out, int *counts);
 
 /* ---- 3b. module-path layers: training-mode BatchNorm, stack tails, pointwise convolution ---- */
 

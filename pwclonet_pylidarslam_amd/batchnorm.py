@@ -13,6 +13,41 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 
+# ``num_batches_tracked += 1`` is one tiny launch per BatchNorm call -- 93 per PWCLO-Net training forward (0.4 ms of kernel
+# time and as many host launches).  Inside ``deferred_counters()`` the calls are only recorded and applied as ONE
+# multi-tensor add when the block ends (a layer called twice in the block gets += 2).  The counters are not read by these
+# kernels (they require ``momentum is not None``), so nothing inside the block can observe the delay.
+_pending = None
+
+
+class deferred_counters:
+    def __enter__(self):
+        global _pending
+        self._outer = _pending
+        _pending = {} if _pending is None else _pending
+        return self
+
+    def __exit__(self, *exc):
+        global _pending
+        pend, _pending = _pending, self._outer
+        if self._outer is None and pend:
+            tensors = [t for t, _ in pend.values()]
+            torch._foreach_add_(tensors, [int(c) for _, c in pend.values()])
+        return False
+
+
+def count_batch(bn):
+    """``bn.num_batches_tracked += 1`` (now, or at the end of the enclosing ``deferred_counters()`` block)."""
+    if not (bn.track_running_stats and bn.num_batches_tracked is not None):
+        return
+    if _pending is None:
+        bn.num_batches_tracked.add_(1)
+    else:
+        t = bn.num_batches_tracked
+        ent = _pending.get(id(t))
+        _pending[id(t)] = (t, (ent[1] if ent else 0) + 1)
+
+
 def _touch(*tensors):
     """The kernels update running_mean / running_var through raw pointers: bump their version counters so that
     anything keyed on them (conv1x1._folded) sees the write."""
@@ -73,8 +108,7 @@ def supported(x, bn):
 def batch_norm_train(x, bn, relu=False):
     """Training-mode forward of the ``torch.nn.BatchNorm*`` module ``bn`` on ``x`` (updates its running statistics
     and ``num_batches_tracked`` like ``bn(x)`` does); ``relu=True`` also applies the stack's ReLU in the same pass."""
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    count_batch(bn)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     y = _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu)
@@ -128,8 +162,7 @@ def supported_maxk(x, bn):
 def batch_norm_train_relu_max(x, bn):
     """``relu(bn(x)).max(dim=3)[0]`` for the training-mode module ``bn`` and x (B, C, S, K): one statistics pass and one
     pooled pass, nothing of shape (B, C, S, K) written."""
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    count_batch(bn)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     y = _BatchNormReluMaxK.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)

@@ -228,8 +228,8 @@ class _BNReluConv(Function):
 def bn_relu_conv(x, bn, conv):
     """``conv(relu(bn(x)))`` for a training-mode ``torch.nn.BatchNorm*`` module ``bn`` (updates its running statistics and
     ``num_batches_tracked`` like ``bn(x)``) and a bias-free pointwise ``conv`` that ``supported(x, conv)`` accepts."""
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    from . import batchnorm as hb
+    hb.count_batch(bn)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     y = _BNReluConv.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, conv.weight)

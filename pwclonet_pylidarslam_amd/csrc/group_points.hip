@@ -76,7 +76,6 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, 
 // streams GP_CHUNK outputs per channel with non-temporal 16-byte stores: the store stream becomes
 // the only HBM-rate traffic.
 constexpr int GP_LDS_MAXN = 4096;     // 8 channels x 4096 floats = 128 KiB of LDS
-constexpr int GP_CHUNK = 4096;        // outputs per channel and workgroup (16 per thread)
 
 // T threads per workgroup; the workgroup streams positions [blockIdx.x * per_wg, +per_wg) of its channel slice.
 // NT: non-temporal stores (the output is never re-read by this kernel).

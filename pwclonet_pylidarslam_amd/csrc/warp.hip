@@ -143,6 +143,46 @@ __global__ __launch_bounds__(256) void compact_frames_kernel(int n, int cap, con
   if (i == n - 1) counts[f] = p < cap ? p : cap;
 }
 
+// The same compaction WITHOUT a precomputed scan (round 3: the scan used to be torch.cumsum, a library kernel on the product
+// path of BASELINE configs[4]): one 1024-thread workgroup per frame; wave w owns a contiguous range of rows and walks it
+// 64 rows at a time (coalesced), a ballot + popcount gives every kept row its slot inside the step, the running sum of
+// popcounts its slot inside the wave's range; the 16 waves' totals are scanned through LDS between a counting pass and
+// the writing pass.  Stable (frame order), same output as the scan + scatter pair.
+__global__ __launch_bounds__(1024) void compact_frames_scan_kernel(int n, int cap, const int *__restrict__ keep,
+                                                                   const float *__restrict__ xyz,
+                                                                   float *__restrict__ out, int *__restrict__ counts) {
+  __shared__ int wave_total[16];
+  const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per_wave = ((n + 15) / 16 + 63) / 64 * 64;          // multiple of 64: steps never straddle two waves' ranges
+  const int i0 = wave * per_wave, i1 = min(n, i0 + per_wave);
+  const int *kf = keep + (size_t)f * n;
+  int total = 0;
+  for (int i = i0 + lane; i - lane < i1; i += 64)
+    total += __popcll(__ballot(i < i1 && kf[i] != 0));
+  if (lane == 0) wave_total[wave] = total;
+  __syncthreads();
+  int base = 0, all = 0;
+  for (int w = 0; w < 16; ++w) {
+    const int t = wave_total[w];
+    if (w < wave) base += t;
+    all += t;
+  }
+  const float *xf = xyz + (size_t)f * n * 3;
+  float *of = out + (size_t)f * cap * 3;
+  for (int i = i0 + lane; i - lane < i1; i += 64) {
+    const bool k = i < i1 && kf[i] != 0;
+    const unsigned long long m = __ballot(k);
+    const int p = base + mbcnt64(m);
+    if (k && p < cap) {
+      of[(size_t)p * 3 + 0] = xf[(size_t)i * 3 + 0];
+      of[(size_t)p * 3 + 1] = xf[(size_t)i * 3 + 1];
+      of[(size_t)p * 3 + 2] = xf[(size_t)i * 3 + 2];
+    }
+    base += __popcll(m);
+  }
+  if (threadIdx.x == 0) counts[f] = all < cap ? all : cap;
+}
+
 }  // namespace pwclo
 
 using namespace pwclo;
@@ -172,6 +212,14 @@ extern "C" void compact_frames_kernel_wrapper(int b, int n, int cap, const int *
   hipLaunchKernelGGL(compact_frames_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, current_stream(), n, cap,
                      keep, pos, xyz, out, counts);
   check_launch("compact_frames");
+}
+
+extern "C" void compact_frames_scan_kernel_wrapper(int b, int n, int cap, const int *keep, const float *xyz, float *out,
+                                                   int *counts) {
+  if (b <= 0 || n <= 0) return;
+  PWCLO_REQUIRE(cap > 0 && (long long)n * 3 < (1ll << 31), "compact_frames_scan: n=%d cap=%d out of range", n, cap);
+  hipLaunchKernelGGL(compact_frames_scan_kernel, dim3(b), dim3(1024), 0, current_stream(), n, cap, keep, xyz, out, counts);
+  check_launch("compact_frames_scan");
 }
 
 extern "C" void ingest_frames_kernel_wrapper(int b, int n, int n_total, int c, const float *frame1,

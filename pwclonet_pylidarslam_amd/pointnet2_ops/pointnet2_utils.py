@@ -160,9 +160,11 @@ class GroupingOperation(Function):
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
+        # the reference returns zeros_like(idx) for the index list (P2/pointnet2_utils.py:237); autograd discards a gradient
+        # for an integer tensor either way, so None saves a fill of up to 8 MB per call (44 calls per training step)
         if deterministic_grads():
-            return _ext.scatter_grad_deterministic(grad_out.contiguous(), idx, ctx.n), torch.zeros_like(idx)
-        return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n), torch.zeros_like(idx)
+            return _ext.scatter_grad_deterministic(grad_out.contiguous(), idx, ctx.n), None
+        return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n), None
 
 
 grouping_operation = GroupingOperation.apply

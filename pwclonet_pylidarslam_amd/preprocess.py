@@ -64,11 +64,11 @@ def compact(xyz, keep, cap=None):
     cap = n if cap is None else int(cap)
     xyz = xyz.contiguous()
     keep = keep.contiguous()
-    pos = torch.cumsum(keep, dim=1, dtype=torch.int32)
     out = torch.zeros((b, cap, 3), dtype=torch.float32, device=xyz.device)
     counts = torch.empty((b,), dtype=torch.int32, device=xyz.device)
-    _lib.call("compact_frames_kernel_wrapper", xyz.device, b, n, cap, keep.data_ptr(), pos.data_ptr(),
-              xyz.data_ptr(), out.data_ptr(), counts.data_ptr())
+    # scan + scatter in one hand-written kernel (csrc/warp.hip: compact_frames_scan_kernel; the scan used to be torch.cumsum)
+    _lib.call("compact_frames_scan_kernel_wrapper", xyz.device, b, n, cap, keep.data_ptr(), xyz.data_ptr(),
+              out.data_ptr(), counts.data_ptr())
     return out, counts
 
 

@@ -188,6 +188,14 @@ class PWCLONet(nn.Module):
                 self.prepare_fused()            # a parameter / buffer was edited in place since packing
             pose, inter = self._fused(xyz_f1, xyz_f2, return_intermediates=True)
             return pose, self._fused_log_dict(inter)
+        if self.training and xyz_f1.is_cuda:
+            from .. import batchnorm as _hip_bn
+            with _hip_bn.deferred_counters():       # the 93 `num_batches_tracked += 1` of a forward as one multi-tensor add
+                return self._forward_modules(xyz_f1, points_f1, xyz_f2, points_f2)
+        return self._forward_modules(xyz_f1, points_f1, xyz_f2, points_f2)
+
+    def _forward_modules(self, xyz_f1, points_f1, xyz_f2, points_f2):
+        """The reference-shaped forward (PW/pwclo_net.py:109-207) on the HIP ops."""
         cf = lambda z: z.permute(0, 2, 1).contiguous()
         B = xyz_f1.size(0)
         if (not self.training) and points_f1 is None and points_f2 is None \
