@@ -402,6 +402,14 @@ def run_config5(args):
     # batches (each on its own stream) fill the chip; never more than two -- a third cooperative launch could not become
     # resident while the first two run and its resident part would wait for its peers until the spin bound.
     depth = max(1, min(2, args.config5_inflight))
+    from pwclonet_pylidarslam_amd.pointnet2_ops import _ext as _ext_mod
+    # spatial order of the large-cloud sampler: the hand-written device kernels (default of the library: faster by 1.1 ms,
+    # cells half the size, one batch in flight 20.6 instead of 21.3 ms) -- except with TWO sampler streams in flight, where the
+    # same kernels measured 12.0 ms per batch against 10.2 ms with the torch-sort front end (profiles/r03/README.md: the slower,
+    # chip-wide front end leaves the pyramids of the other batch a window; padding the device path by 1.1 ms recovers half of
+    # the difference).  `--config5-order` overrides; the choice is reported in config.spatial_order.
+    order = args.config5_order if args.config5_order != "auto" else ("torch" if depth > 1 else "device")
+    _ext_mod.LARGE_CLOUD_ORDER = order
     if depth > 1:
         # two samplers side by side need the plain launch: the cooperative-launch API has one queue per device and would
         # run them one after the other (include/pwclo_ops.h: pwclo_fps_large_cloud_launch); at most 2 x 128 workgroups
@@ -497,7 +505,9 @@ def run_config5(args):
                    "global_batch": world * B, "npoints": npts, "parallelism": "replicas x%d" % world,
                    "launch": "eager; large-cloud sampler: %s" % ("plain launch, two batches in flight on two streams"
                                                                   if depth > 1 else "cooperative launch, one batch in flight"),
-                   "batches_in_flight": depth, "pyramids_on_their_own_stream": bool(pyr is not None)},
+                   "batches_in_flight": depth, "pyramids_on_their_own_stream": bool(pyr is not None),
+                   "spatial_order": order + (" (torch argsort front end: see profiles/r03/README.md)" if order == "torch"
+                                             else " (csrc/sampling.hip fps_spatial_order kernels)")},
         "stages_ms": {"kitti360_filter": t_filter, "compaction": t_compact, "fps_%d_to_%d" % (n_surv, npts): t_fps,
                       "pyramid_kernels_%s" % args.dtype: t_pyr},
         "roofline": {"kernel": "fps_coop_kernel<16>", "bound": "hbm",
@@ -560,6 +570,9 @@ def main():
                     help="graph = replay one captured hipGraph per step (default); eager = Python launches")
     ap.add_argument("--config5-inflight", type=int, default=2,
                     help="--config 5: batches in flight, 1 or 2 (each sampler launch occupies half of the CUs)")
+    ap.add_argument("--config5-order", default="auto", choices=["auto", "device", "torch"],
+                    help="--config 5: how the large-cloud sampler's spatial order is built (auto: device kernels with one batch "
+                         "in flight, torch sorts with two -- measured faster there)")
     ap.add_argument("--config5-split", type=int, default=1,
                     help="--config 5 with two batches in flight: 1 = pyramids on a third stream (sampler streams run only "
                          "front ends)")

@@ -161,6 +161,11 @@ void knn_point_prebuilt_kernel_wrapper(int b, int n, int s, int nsample, const f
  * searches one frame's half of it without rebuilding).  new_xyz (b,s,3), idx (b,s,nsample). */
 void knn_point_prebuilt_slice_kernel_wrapper(int b, int n, int s, int nsample, const float *new_xyz, int *idx,
                                              float *dist, void *workspace, int first_cloud, int built_b);
+/* The spatial order the sorted sampler below wants, built on the device: points (b,n,3) -> sorted (b,n,3), perm (b,n);
+ * workspace of fps_spatial_order_workspace_bytes(b, n) bytes.  (32^3 Morton cells by counting sort, then every block of
+ * 1024 consecutive positions sorted by sampling priority; any such order is exact for the sampler.) */
+long long fps_spatial_order_workspace_bytes(int b, int n);
+void fps_spatial_order_kernel_wrapper(int b, int n, const float *points, float *sorted, int *perm, void *workspace);
 /* Large clouds (n > 24576) presented in a spatially coherent order: sorted (b,n,3) = dataset gathered by perm (b,n),
  * perm[p] = original index of sorted position p; inside every block of 1024 consecutive positions the positions are
  * ordered by ascending sampling priority (bitrev(k mod bs) << 23 | k div bs of the original index k).  A wave of the

@@ -58,6 +58,8 @@ SIGNATURES = {
     "kitti_transform_filter_kernel_wrapper": ([_i, _F, _F, _F, _F], None),
     "kitti360_filter_kernel_wrapper": ([_i, ctypes.c_float, ctypes.c_float, _F, _F, _F], None),
     "compact_frames_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F, _F], None),
+    "fps_spatial_order_workspace_bytes": ([_i, _i], ctypes.c_longlong),
+    "fps_spatial_order_kernel_wrapper": ([_i, _i, _F, _F, _F, _F], None),
     "compact_frames_scan_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F], None),
     "batchnorm_train_workspace_bytes": ([_i], ctypes.c_longlong),
     "batchnorm_train_forward_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, ctypes.c_float, ctypes.c_float, _F, _F, _F, _F,

@@ -1197,6 +1197,200 @@ extern "C" void furthest_point_sampling_sorted_kernel_wrapper(int b, int n, int 
   coop_launch(b, n, m, bs, log2bs, G, sorted, reinterpret_cast<unsigned long long *>(temp), idxs, new_xyz, perm, dataset);
 }
 
+// ---- spatial order for the large-cloud sampler, on the device (round 3) -----------------------------------------------
+// The order furthest_point_sampling_sorted_kernel_wrapper wants -- spatially compact cells of 1024 consecutive positions,
+// each ordered by ascending sampling priority -- used to be built with torch sorts (two argsorts + a scatter: library
+// kernels on the product path of BASELINE configs[4]).  Hand-written replacement, five small kernels:
+//   bounding box per cloud -> Morton code of every point's 32 x 32 x 32 cell + histogram of the 32768 cells (global atomics)
+//   -> exclusive scan of the histogram (one workgroup per cloud) -> counting-sort scatter (atomic cursor per cell: the order
+//   INSIDE a cell is whatever the atomics give, which is fine -- any order is exact, see below) -> per block of 1024
+//   consecutive positions a bitonic sort by priority in LDS, writing `perm` and the gathered coordinates.
+// Exactness does not depend on WHICH order comes out: the sampler's pruning test is exact for any partition into cells and
+// the per-cell priority order keeps the reference's tie rule; a better order only prunes more.
+namespace pwclo {
+constexpr int SO_BITS = 18;                 // cell-code bits (handed out to the axes by the cloud's aspect ratio)
+constexpr int SO_CELLS = 1 << SO_BITS;
+constexpr int SO_BINS = SO_CELLS + 1024;     // + one bin (and padding to a multiple of 1024) for the never-eligible rows
+
+// order-preserving map float -> unsigned (so that atomicMin / atomicMax on the code give the float min / max)
+__device__ __forceinline__ unsigned so_code(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float so_decode(unsigned c) {
+  return __uint_as_float((c & 0x80000000u) ? (c & 0x7FFFFFFFu) : ~c);
+}
+
+// box (b,8) as CODES: [0..2] min per axis (initialised 0xFFFFFFFF), [4..6] max per axis (initialised 0)
+__global__ __launch_bounds__(256) void so_bbox_kernel(int n, const float *__restrict__ pts, unsigned *__restrict__ box) {
+  const int b = blockIdx.y;
+  const float *p = pts + (size_t)b * n * 3;
+  unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float px = p[(size_t)i * 3], py = p[(size_t)i * 3 + 1], pz = p[(size_t)i * 3 + 2];
+    if ((double)((px * px) + (py * py) + (pz * pz)) <= 1e-3) continue;     // never-eligible rows stay outside the box
+    const float v[3] = {px, py, pz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const unsigned c = so_code(v[a]); lo[a] = min(lo[a], c); hi[a] = max(hi[a], c); }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = wave_allreduce_u32(lo[a], [](unsigned x, unsigned y) { return x < y ? x : y; });
+    hi[a] = wave_allreduce_u32(hi[a], [](unsigned x, unsigned y) { return x > y ? x : y; });
+  }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { atomicMin(box + b * 8 + a, lo[a]); atomicMax(box + b * 8 + 4 + a, hi[a]); }
+}
+
+// boxes to (min = +max code, max = 0) and the histograms to 0 in one launch (no hipMemsetAsync: the runtime's fill path
+// serialised the two sampler streams of configs[4] against each other)
+__global__ void so_init_kernel(unsigned *box, int nbox, int *hist, int nhist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nbox) box[i] = (i & 4) ? 0u : 0xFFFFFFFFu;
+  for (int k = i; k < nhist; k += gridDim.x * blockDim.x) hist[k] = 0;
+}
+
+
+__global__ __launch_bounds__(256) void so_hist_kernel(int n, const float *__restrict__ pts, const unsigned *__restrict__ box,
+                                                      int *__restrict__ cell, int *__restrict__ hist) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float *p = pts + ((size_t)b * n + i) * 3;
+  const unsigned *bx = box + b * 8;
+  // SO_BITS bits of cell code, handed out coarse to fine to whichever axis currently has the LARGEST cell (lidar clouds are
+  // 160 m x 160 m x 4 m slabs: equal bits per axis would spend a third of them slicing the slab into 15 cm layers); the
+  // order of the hand-outs is the bit order of the code, i.e. a Morton curve on the cloud's own aspect ratio
+  float lo[3], size[3];
+  int bits[3] = {0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { lo[a] = so_decode(bx[a]); size[a] = fmaxf(so_decode(bx[4 + a]) - lo[a], 1e-20f); }
+  const float span[3] = {size[0], size[1], size[2]};
+  unsigned long long seq = 0ull;                 // 2 bits per hand-out, first hand-out in the top bits
+#pragma unroll
+  for (int t = 0; t < SO_BITS; ++t) {
+    const int a = (size[0] >= size[1] && size[0] >= size[2]) ? 0 : (size[1] >= size[2] ? 1 : 2);
+    seq = (seq << 2) | (unsigned long long)a;
+    size[a] *= 0.5f;
+    bits[a] += 1;
+  }
+  int q[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int cells = 1 << bits[a];
+    int v = (int)((p[a] - lo[a]) * ((float)cells / span[a]));
+    q[a] = v < 0 ? 0 : (v >= cells ? cells - 1 : v);
+  }
+  unsigned c = 0u;
+  int left[3] = {bits[0], bits[1], bits[2]};
+#pragma unroll
+  for (int t = SO_BITS - 1; t >= 0; --t) {
+    const int a = (int)((seq >> (2 * t)) & 3ull);
+    left[a] -= 1;
+    c = (c << 1) | (unsigned)((q[a] >> left[a]) & 1);
+  }
+  // rows the sampler never selects (|p|^2 <= 1e-3: the zero padding behind a frame's survivors, sampling.cpp:74-76) go
+  // behind every real cell: mixed into the origin's cell they would smear its few real points over dozens of blocks
+  const float mag = (p[0] * p[0]) + (p[1] * p[1]) + (p[2] * p[2]);
+  if ((double)mag <= 1e-3) c = (unsigned)SO_CELLS;
+  cell[(size_t)b * n + i] = (int)c;
+  atomicAdd(hist + (size_t)b * SO_BINS + c, 1);
+}
+
+// hist (b, SO_CELLS) -> exclusive scan in place (the counting sort's cursors); one 1024-thread workgroup per cloud
+__global__ __launch_bounds__(1024) void so_scan_kernel(int *__restrict__ hist) {
+  __shared__ int wsum[16];
+  int *h = hist + (size_t)blockIdx.x * SO_BINS;
+  constexpr int PER = SO_BINS / 1024;
+  int v[PER], tot = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { v[k] = h[threadIdx.x * PER + k]; tot += v[k]; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = inc - tot;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { h[threadIdx.x * PER + k] = base; base += v[k]; }
+}
+
+__global__ __launch_bounds__(256) void so_scatter_kernel(int n, const int *__restrict__ cell, int *__restrict__ cursor,
+                                                         int *__restrict__ order) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = cell[(size_t)b * n + i];
+  const int pos = atomicAdd(cursor + (size_t)b * SO_BINS + c, 1);
+  order[(size_t)b * n + pos] = i;
+}
+
+// positions [1024 * blockIdx.x, +1024) of cloud blockIdx.y: sorted by ascending sampling priority of their original index
+__global__ __launch_bounds__(1024) void so_block_sort_kernel(int n, int bs, int log2bs, const int *__restrict__ order,
+                                                             const float *__restrict__ pts, float *__restrict__ sorted,
+                                                             int *__restrict__ perm) {
+  __shared__ unsigned long long key[1024];
+  const int b = blockIdx.y, t = threadIdx.x, pos = blockIdx.x * 1024 + t;
+  unsigned long long k = ~0ull;
+  if (pos < n) {
+    const unsigned o = (unsigned)order[(size_t)b * n + pos];
+    const unsigned pri = (fps_bitrev(o & (unsigned)(bs - 1), log2bs) << PRI_SHIFT) | (o >> log2bs);
+    k = ((unsigned long long)pri << 32) | o;
+  }
+  key[t] = k;
+  __syncthreads();
+  for (int size = 2; size <= 1024; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int partner = t ^ stride;
+      if (partner > t) {
+        const unsigned long long a = key[t], c = key[partner];
+        const bool up = (t & size) == 0;
+        if ((a > c) == up) { key[t] = c; key[partner] = a; }
+      }
+      __syncthreads();
+    }
+  if (pos < n) {
+    const unsigned o = (unsigned)(key[t] & 0xFFFFFFFFull);
+    perm[(size_t)b * n + pos] = (int)o;
+    const float *src = pts + ((size_t)b * n + o) * 3;
+    float *dst = sorted + ((size_t)b * n + pos) * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+  }
+}
+}  // namespace pwclo
+
+extern "C" long long fps_spatial_order_workspace_bytes(int b, int n) {
+  return ((long long)b * 8 + (long long)b * n * 2 + (long long)b * pwclo::SO_BINS) * 4;     // box, cell, order, histogram
+}
+
+// points (b,n,3) -> sorted (b,n,3), perm (b,n) i32 as furthest_point_sampling_sorted_kernel_wrapper wants them; `workspace`
+// of fps_spatial_order_workspace_bytes(b, n) bytes.  Five launches on the current stream, no host synchronisation.
+extern "C" void fps_spatial_order_kernel_wrapper(int b, int n, const float *points, float *sorted, int *perm,
+                                                 void *workspace) {
+  if (b <= 0 || n <= 0) return;
+  PWCLO_REQUIRE(workspace != nullptr && points != nullptr && sorted != nullptr && perm != nullptr,
+                "fps_spatial_order: points, outputs and workspace are required%s", "");
+  PWCLO_REQUIRE(b <= 65535 && (long long)n < (1ll << PRI_SHIFT), "fps_spatial_order: b=%d n=%d out of range", b, n);
+  const int bs = ref_opt_n_threads(n);
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  unsigned *box = reinterpret_cast<unsigned *>(workspace);
+  int *cell = reinterpret_cast<int *>(box + (size_t)b * 8);
+  int *order = cell + (size_t)b * n;
+  int *hist = order + (size_t)b * n;
+  hipStream_t st = current_stream();
+  hipLaunchKernelGGL(so_init_kernel, dim3(max(ceil_div(b * 8, 256), min(1024, ceil_div(b * SO_BINS, 1024)))), dim3(256), 0, st, box,
+                     b * 8, hist, b * SO_BINS);
+  hipLaunchKernelGGL(so_bbox_kernel, dim3(32, b), dim3(256), 0, st, n, points, box);
+  hipLaunchKernelGGL(so_hist_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, n, points, box, cell, hist);
+  hipLaunchKernelGGL(so_scan_kernel, dim3(b), dim3(1024), 0, st, hist);
+  hipLaunchKernelGGL(so_scatter_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, n, cell, hist, order);
+  hipLaunchKernelGGL(so_block_sort_kernel, dim3(ceil_div(n, 1024), b), dim3(1024), 0, st, n, bs, log2bs, order, points, sorted,
+                     perm);
+  check_launch("fps_spatial_order");
+}
+
 extern "C" int knn_point_slabs(int n);
 extern "C" long long knn_point_build_bytes(int b, int n);
 

@@ -62,7 +62,13 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
+# How the large-cloud sampler's spatial order is built: "device" = the hand-written kernels of csrc/sampling.hip
+# (fps_spatial_order: 0.4 ms for 16 clouds of 120 000 rows, cells half the size), "torch" = two torch argsorts + a scatter
+# (1.5 ms; library sorts).  Either order gives bit-identical samples.  bench.py --config 5 documents the one case that still
+# picks "torch" (two sampler streams in flight) and why.
+LARGE_CLOUD_ORDER = "torch" if _os.environ.get("PWCLO_FPS_ORDER_TORCH", "0") != "0" else "device"
 _PRI_TABLES = {}
+_ORDER_BUFFERS = {}      # (device, stream, B, N) -> (workspace, sorted points, permutation) of _fps_sorted_order
 
 
 def _fps_priorities(n, device):
@@ -86,6 +92,26 @@ def _fps_sorted_order(points):
     points (B,N,3) -> (sorted (B,N,3) f32, perm (B,N) i32: original index of every sorted position).  Torch sorts:
     plumbing around the kernel, ~0.3 ms for 16 clouds of 1e5 points against the 8 ms the pruned update saves."""
     B, N, _ = points.shape
+    if LARGE_CLOUD_ORDER == "device":
+        # hand-written counting sort + per-cell priority sort (csrc/sampling.hip: fps_spatial_order); the torch sorts below
+        # are kept as the A/B reference (PWCLO_FPS_ORDER_TORCH=1) -- either order is exact for the sampler
+        lib = _lib.load()
+        # the three scratch / output buffers are only read by the sampler launched next on THIS stream, so one set per
+        # (stream, shape) is reused call after call: with several sampler streams in flight the caching allocator otherwise
+        # keeps asking the runtime for memory (blocks handed between streams are not reusable at once) and every such
+        # hipMalloc stalls the device
+        key = (str(points.device), torch.cuda.current_stream(points.device).cuda_stream, B, N)
+        bufs = _ORDER_BUFFERS.get(key)
+        if bufs is None or torch.cuda.is_current_stream_capturing():
+            bufs = (torch.empty((lib.fps_spatial_order_workspace_bytes(B, N),), dtype=torch.uint8, device=points.device),
+                    torch.empty_like(points), torch.empty((B, N), dtype=torch.int32, device=points.device))
+            if not torch.cuda.is_current_stream_capturing():
+                if len(_ORDER_BUFFERS) >= 8:
+                    _ORDER_BUFFERS.clear()
+                _ORDER_BUFFERS[key] = bufs
+        ws, sorted_pts, perm = bufs
+        _lib.call("fps_spatial_order_kernel_wrapper", points.device, B, N, _p(points), _p(sorted_pts), _p(perm), _p(ws))
+        return sorted_pts, perm
     lo = points.amin(dim=1, keepdim=True)
     span = (points.amax(dim=1, keepdim=True) - lo).clamp_min(1e-20)
     q = ((points - lo) * (1023.0 / span)).to(torch.int64).clamp_(0, 1023)

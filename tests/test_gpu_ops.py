@@ -92,6 +92,21 @@ def test_fps_batch16_ties_and_padding(cuda):
     assert torch.equal(out, ref)
 
 
+def test_fps_large_cloud_spatial_orders_agree(cuda, monkeypatch):
+    """The large-cloud sampler's spatial order comes from hand-written kernels (csrc/sampling.hip fps_spatial_order: counting
+    sort into aspect-aware Morton cells + a priority sort per 1024 positions) or, as the A/B reference, from torch sorts:
+    any such order is exact, so both give the oracle's indices -- also with zero padding and on a tie lattice."""
+    from pwclonet_pylidarslam_amd.pointnet2_ops import _ext as ext
+    gen = torch.Generator().manual_seed(77)
+    x = (torch.rand(2, 40000, 3, generator=gen) * 2 - 1) * torch.tensor([60.0, 60.0, 2.0])
+    x[0, 30000:] = 0.0
+    x[1] = torch.randint(-12, 13, (40000, 3), generator=gen).float()
+    ref = O.furthest_point_sampling(x, 96)
+    for order in ("device", "torch"):
+        monkeypatch.setattr(ext, "LARGE_CLOUD_ORDER", order)
+        assert torch.equal(ext.furthest_point_sampling(g(x, cuda), 96).cpu(), ref), order
+
+
 @pytest.mark.parametrize("b,n,m,lattice", [(3, 30000, 150, 0), (2, 40001, 120, 9), (9, 25000, 40, 0),
                                            # BASELINE configs[4] at its real size (G = 8 workgroups per cloud, 8191
                                            # alternations of the two exchange slot sets): random, a lattice with
