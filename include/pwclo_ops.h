@@ -468,6 +468,15 @@ void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xyz1, const f
                                  const float *v2, const float *first, const int *idx,
                                  const float *packed_w, float *out, int wfmt, int packed_floats);
 
+/* ---- 4b. module path (training): softmax over K + weighted sum as one pass each way ---------------------------
+ * out[r] = sum_k softmax_k(x[r,:]) * v[r,k] for rows = B*C*S contiguous rows of K logits / values (PW/costvolume.py:139-141,
+ * 181-183 on (B,C,S,K) tensors); backward recomputes the probabilities: dv = dout p, dx = p dout (v - out).
+ * K in {1,2,4,6,8,16,32} (softmax_wsum_supported_k), 16-byte aligned tensors. */
+int softmax_wsum_supported_k(int k);
+void softmax_wsum_forward_kernel_wrapper(long long rows, int k, const float *x, const float *v, float *out);
+void softmax_wsum_backward_kernel_wrapper(long long rows, int k, const float *x, const float *v, const float *dout,
+                                          float *dx, float *dv);
+
 /* ---- 5. KITTI odometry evaluation of predicted poses ---------------------------
  * Replaces the per-sample host loops of /root/reference/train.py:866-893 (pose row -> 4x4 via quat2mat :762-795),
  * slam/common/kitti360_utils.py:406-431 (relative -> absolute poses), evaluation.py:198-215 (trajectory distances)

@@ -60,6 +60,9 @@ SIGNATURES = {
     "compact_frames_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F, _F], None),
     "fps_spatial_order_workspace_bytes": ([_i, _i], ctypes.c_longlong),
     "fps_spatial_order_kernel_wrapper": ([_i, _i, _F, _F, _F, _F], None),
+    "softmax_wsum_supported_k": ([_i], _i),
+    "softmax_wsum_forward_kernel_wrapper": ([ctypes.c_longlong, _i, _F, _F, _F], None),
+    "softmax_wsum_backward_kernel_wrapper": ([ctypes.c_longlong, _i, _F, _F, _F, _F, _F], None),
     "compact_frames_scan_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, _F], None),
     "batchnorm_train_workspace_bytes": ([_i], ctypes.c_longlong),
     "batchnorm_train_forward_kernel_wrapper": ([_i, _i, _i, _F, _F, _F, ctypes.c_float, ctypes.c_float, _F, _F, _F, _F,

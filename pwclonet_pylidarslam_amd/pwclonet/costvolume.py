@@ -5,6 +5,7 @@ import torch.nn.functional as F
 
 from ..pointnet2_ops import pointnet2_utils as pointutils
 from ..pointnet2_ops import pytorch_utils as pt_utils
+from ..softmax_wsum import softmax_weighted_sum
 
 
 def _geometry(centre_xyz, grouped_xyz):
@@ -48,8 +49,8 @@ class CostVolume(nn.Module):
         p_pts = warped_points.unsqueeze(3).expand(-1, -1, -1, kq)
         feat = self.mlp_convs(torch.cat((geo, p_pts, q_pts), dim=1))
         enc = self.mlp_conv_xyz_1(geo)
-        w = F.softmax(self.mlp2_convs(torch.cat((enc, feat), dim=1)), dim=3)
-        first = torch.sum(w * feat, dim=3)
+        # softmax over the neighbours + weighted sum (costvolume.py:139-141) as one kernel each way on the GPU
+        first = softmax_weighted_sum(self.mlp2_convs(torch.cat((enc, feat), dim=1)), feat)
 
         # second aggregate: frame-1 neighbours of every frame-1 point
         _, idx = pt_utils.knn_point(k, warped_xyz_t, warped_xyz_t)
@@ -57,5 +58,4 @@ class CostVolume(nn.Module):
         c_pts = pointutils.grouping_operation(first.contiguous(), idx)
         enc2 = self.mlp_conv_xyz_2(_geometry(warped_xyz, c_xyz))
         p_pts2 = warped_points.unsqueeze(3).expand(-1, -1, -1, k)
-        w2 = F.softmax(self.mlp3_convs(torch.cat((enc2, p_pts2, c_pts), dim=1)), dim=3)
-        return torch.sum(w2 * c_pts, dim=3)
+        return softmax_weighted_sum(self.mlp3_convs(torch.cat((enc2, p_pts2, c_pts), dim=1)), c_pts)   # :181-183

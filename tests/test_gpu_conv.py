@@ -67,6 +67,23 @@ def test_conv1x1_ragged_pixel_counts(cuda, B, P):
         _check(dw, rdw, "dw")
 
 
+@pytest.mark.parametrize("cin,cout", [(1, 1), (3, 4), (2, 5)])
+@pytest.mark.parametrize("P", [4, 64, 128])
+def test_conv1x1_few_channels_few_pixels(cuda, cin, cout, P):
+    """with fewer than 8 rows (cin + cout) and <= 128 pixels the weight gradient's phase reduction reused a
+    staging area smaller than its 8 KiB of phase sums (stores beyond the reserved LDS were dropped: dW came back wrong,
+    silently).  wgrad_plan now reserves max(staging, phase sums); these are the shapes that reached it."""
+    g = torch.Generator().manual_seed(1000 * cin + 10 * cout + P)
+    x = torch.randn(2, cin, P, generator=g).to(cuda)
+    w = torch.randn(cout, cin, generator=g).to(cuda)
+    dy = torch.randn(2, cout, P, generator=g).to(cuda)
+    y, dx, dw = _run(x, w, dy)
+    ry, rdx, rdw = _ref(x, w, dy)
+    _check(y, ry, "y")
+    _check(dx, rdx, "dx")
+    _check(dw, rdw, "dw")
+
+
 def test_conv1x1_large_layer_is_deterministic_and_close_to_torch(cuda):
     """A full-size layer of the level-1 set-upconv (B=8 here): 128 -> 128 over 131072 pixels.  Two runs are
     bit-identical (fixed summation order, no atomics); against torch's own convolution the three results agree to the
@@ -383,3 +400,27 @@ def test_training_stack_without_normalised_activations_matches_torch(cuda, poole
             assert (p.double() - q).abs().max().item() <= 1e-5 * max(q.abs().max().item(), 1.0), n
         else:
             assert int(p) == 1, n                             # num_batches_tracked (the float64 copy was not advanced)
+
+
+@pytest.mark.parametrize("K", [4, 6, 32, 8])
+def test_softmax_weighted_sum_matches_torch(cuda, K):
+    """csrc/softmax_wsum.hip behind pwclonet/costvolume.py: sum(softmax(x, dim=3) * v, dim=3), forward and both gradients,
+    against the float64 evaluation of the three torch ops (PW/costvolume.py:139-141, 181-183); ragged row counts; a K the
+    kernel is not built for falls back to torch."""
+    from pwclonet_pylidarslam_amd.softmax_wsum import softmax_weighted_sum
+    g = torch.Generator().manual_seed(40 + K)
+    for shape in ((2, 64, 301, K), (1, 3, 7, K)):
+        x = (torch.randn(shape, generator=g) * 3).to(cuda).requires_grad_(True)
+        v = torch.randn(shape, generator=g).to(cuda).requires_grad_(True)
+        go = torch.randn(shape[:3], generator=g).to(cuda)
+        out = softmax_weighted_sum(x, v)
+        out.backward(go)
+        x64, v64 = x.detach().double().requires_grad_(True), v.detach().double().requires_grad_(True)
+        ref = torch.sum(torch.softmax(x64, dim=3) * v64, dim=3)
+        ref.backward(go.double())
+        _check(out.detach(), ref.detach(), "out", rel=2e-6)
+        _check(x.grad, x64.grad, "dx", rel=2e-6)
+        _check(v.grad, v64.grad, "dv", rel=2e-6)
+    x = torch.randn(2, 5, 9, 5, generator=g).to(cuda)            # K = 5: torch ops
+    v = torch.randn(2, 5, 9, 5, generator=g).to(cuda)
+    torch.testing.assert_close(softmax_weighted_sum(x, v), torch.sum(torch.softmax(x, dim=3) * v, dim=3))
