@@ -152,20 +152,43 @@ def annotate(**meta):
     _meta = meta
 
 
+_fn_cache = {}
+
+
 def call(name, device, *args):
-    """Launch `name` on torch's current stream of `device` and check the sticky error."""
+    """Launch `name` on torch's current stream of `device` and check the sticky error.
+    (The host cost of this function is the floor of every eager launch: function pointers are looked up once, the device
+    guard is skipped when `device` already is the current one.)"""
     global _meta
-    lib = load()
-    with torch.cuda.device(device):
-        stream = torch.cuda.current_stream(device)
-        lib.pwclo_set_stream(ctypes.c_void_p(stream.cuda_stream))
+    fn = _fn_cache.get(name)
+    if fn is None:
+        lib = load()
+        fn = _fn_cache[name] = (getattr(lib, name), lib.pwclo_set_stream, lib.pwclo_last_error)
+    launch, set_stream, last_error = fn
+    idx = device.index if isinstance(device, torch.device) and device.index is not None else None
+    if idx is None or idx == torch.cuda.current_device():
+        stream = torch.cuda.current_stream()
+        set_stream(stream.cuda_stream)
         if profiler is None:
-            getattr(lib, name)(*args)
+            launch(*args)
         else:   # HIP events on the very stream the kernel is launched on
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(stream)
-            getattr(lib, name)(*args)
+            launch(*args)
             e.record(stream)
             profiler.add(name, _meta, s, e)
+    else:
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device)
+            set_stream(stream.cuda_stream)
+            if profiler is None:
+                launch(*args)
+            else:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(stream)
+                launch(*args)
+                e.record(stream)
+                profiler.add(name, _meta, s, e)
     _meta = None
-    check(name)
+    if last_error() != 0:
+        check(name)
