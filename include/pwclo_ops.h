@@ -316,6 +316,20 @@ void group_points_grad_sorted_kernel_wrapper(int b, int c, int n, int npoints, i
                                              const float *grad_out, const int *perm, const int *seg,
                                              float *grad_points);
 
+/* Channel-slice forms of the three grouping entry points.  The reference concatenates every grouped tensor with the
+ * coordinate differences / the other frame's features before the shared MLP (P2/pointnet2_modules.py:222-230, 490-500;
+ * PW/costvolume.py:107, 134, 172), i.e. it writes the grouped tensor, then copies it into the concatenated one, and in
+ * backward copies the slice of the gradient back out.  Here `out` / `grad_out` point at channel `c_off` of cloud 0 of a
+ * (b, c_total, npoints, nsample) tensor and `batch_stride` = c_total * npoints * nsample floats: the kernels group
+ * straight into / differentiate straight out of the concatenated tensor.  Values are those of the dense entry points. */
+void group_points_strided_kernel_wrapper(int b, int c, int n, int npoints, int nsample, const float *points,
+                                         const int *idx, float *out, long long batch_stride);
+void group_points_grad_strided_kernel_wrapper(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                              long long batch_stride, const int *idx, float *grad_points);
+void group_points_grad_sorted_strided_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                                     const float *grad_out, long long batch_stride, const int *perm,
+                                                     const int *seg, float *grad_points);
+
 /* On-device front end of the dataset (slam/dataset/kitti_odometry_dataset.py:375-397, filter_pcd
  * :149-160): points (n,4) f32 raw velodyne rows (x,y,z,intensity), tr (12) f64 DEVICE array = rows of the
  * 3x4 calibration matrix Tr; xyz (n,3) f32 = Tr . (x,y,z,1) evaluated in fp64, keep (n) i32 = 1 where the

@@ -79,6 +79,9 @@ SIGNATURES = {
     "conv1x1_wgrad_workspace_bytes": ([_i, _i, _i, _i], ctypes.c_longlong),
     "conv1x1_wgrad_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
     "group_points_grad_sorted_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, _F, _F, _F], None),
+    "group_points_strided_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, _F, _F, ctypes.c_longlong], None),
+    "group_points_grad_strided_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, ctypes.c_longlong, _F, _F], None),
+    "group_points_grad_sorted_strided_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, ctypes.c_longlong, _F, _F, _F], None),
     "upconv_fused_kernel_wrapper": ([_i] * 4 + [_F] * 6, None),
     "pointwise_fused_kernel_wrapper": ([_i] * 7 + [_F] * 5, None),
     "cv_fused_a1_kernel_wrapper": ([_i] * 5 + [_F] * 7 + [_i], None),

@@ -60,7 +60,7 @@ def _compile(src, force, trace=False):
 def source_stamp():
     """sha256 (first 16 hex digits) over everything that decides what the FUSED FORWARD's kernels do and how much memory
     they touch -- the path the PMC artefacts describe: the stack / sampler / neighbour-search / warp sources of csrc/, their
-    shared headers, the C ABI header and the host-side packing / launch code (fused.py).  The training-only kernels
+    shared headers and the host-side packing / launch code (fused.py).  The training-only kernels
     (conv1x1, batchnorm) and the stand-alone ext ops are not part of it.  Profile artefacts that bench.py reports beside
     live timings (profiles/pmc_*.json) carry the stamp of the tree they were measured on; bench.py marks them stale when
     it differs from the running tree's."""
@@ -68,8 +68,7 @@ def source_stamp():
     h = hashlib.sha256()
     names = ("common.hpp", "mlp_core.hpp", "fused_hoisted.hip", "fused_layers.hip", "fused_sa.hip", "knn.hip",
              "sampling.hip", "warp.hip", "state.hip")
-    files = [os.path.join(CSRC, f) for f in names]
-    files += [os.path.join(os.path.dirname(HERE), "include", "pwclo_ops.h"), os.path.join(HERE, "fused.py")]
+    files = [os.path.join(CSRC, f) for f in names] + [os.path.join(HERE, "fused.py")]   # (the ABI header only declares)
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:

@@ -22,7 +22,7 @@ template <bool VEC4>
 __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, int P,
                                                                   const float *__restrict__ points,
                                                                   const int *__restrict__ idx,
-                                                                  float *__restrict__ out) {
+                                                                  float *__restrict__ out, long long out_bstride) {
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * GP_CH_PER_BLOCK;
   const int c1 = min(c0 + GP_CH_PER_BLOCK, c);
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, 
     if (p >= P) return;
     const int4 ii = *reinterpret_cast<const int4 *>(ib + p);
     const float *row0 = points + ((size_t)b * c + c0) * n;
-    float *out0 = out + ((size_t)b * c + c0) * P + p;
+    float *out0 = out + (size_t)b * out_bstride + (size_t)c0 * P + p;
     if (c1 - c0 == GP_CH_PER_BLOCK) {
       // full channel slice: all 32 gathers are in flight before the first store; the output is a
       // pure stream (never re-read by this kernel) and goes out non-temporal so that it does not
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, 
     if (p >= P) return;
     const int ii = ib[p];
     for (int l = c0; l < c1; ++l)
-      out[((size_t)b * c + l) * P + p] = points[((size_t)b * c + l) * n + ii];
+      out[(size_t)b * out_bstride + (size_t)l * P + p] = points[((size_t)b * c + l) * n + ii];
   }
 }
 
@@ -83,7 +83,7 @@ template <int T, bool NT>
 __global__ __launch_bounds__(T) void group_points_lds_kernel(int c, int n, int P, int per_wg,
                                                              const float *__restrict__ points,
                                                              const int *__restrict__ idx,
-                                                             float *__restrict__ out) {
+                                                             float *__restrict__ out, long long out_bstride) {
   extern __shared__ __attribute__((aligned(16))) float rows[];   // [GP_CH_PER_BLOCK][n]
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * GP_CH_PER_BLOCK;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(T) void group_points_lds_kernel(int c, int n, int P
     for (int i = threadIdx.x; i < total; i += T) rows[i] = src[i];
   }
   __syncthreads();
-  float *ob = out + ((size_t)b * c + c0) * P;
+  float *ob = out + (size_t)b * out_bstride + (size_t)c0 * P;     // out_bstride = c * P for a dense (B, C, S, K) result
   for (; p < p_end; p += T * 4) {
     const int pn = p + T * 4;
     int4 inext = ii;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(T) void group_points_lds_kernel(int c, int n, int P
 // grad_points[b,c,idx[b,p]] += grad_out[b,c,p]  (fp32 atomics into a zero-filled buffer).
 __global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(
     int c, int n, int P, const float *__restrict__ grad_out, const int *__restrict__ idx,
-    float *__restrict__ grad_points) {
+    float *__restrict__ grad_points, long long go_bstride) {
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * GP_CH_PER_BLOCK;
   const int c1 = min(c0 + GP_CH_PER_BLOCK, c);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(
   if (p >= P) return;
   const int ii = idx[(size_t)b * P + p];
   for (int l = c0; l < c1; ++l)
-    atomicAdd(grad_points + ((size_t)b * c + l) * n + ii, grad_out[((size_t)b * c + l) * P + p]);
+    atomicAdd(grad_points + ((size_t)b * c + l) * n + ii, grad_out[(size_t)b * go_bstride + (size_t)l * P + p]);
 }
 
 // Same sums through LDS: a workgroup owns (cloud b, a slice of CT channels, a contiguous range of positions
@@ -151,7 +151,7 @@ constexpr int GG_LDS_BYTES = 128 * 1024;
 
 __global__ __launch_bounds__(GG_THREADS) void group_points_grad_lds_kernel(
     int c, int n, int P, int ct, int per_split, int vec4, const float *__restrict__ grad_out,
-    const int *__restrict__ idx, float *__restrict__ grad_points) {
+    const int *__restrict__ idx, float *__restrict__ grad_points, long long go_bstride) {
   extern __shared__ __attribute__((aligned(16))) float gg_acc[];
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * ct;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_points_grad_lds_kernel(
   __syncthreads();
   const int p0 = blockIdx.x * per_split, p1 = min(P, p0 + per_split);
   const int *ib = idx + (size_t)b * P;
-  const float *g0 = grad_out + ((size_t)b * c + c0) * P;
+  const float *g0 = grad_out + (size_t)b * go_bstride + (size_t)c0 * P;     // go_bstride = c * P for a dense gradient
   auto add = [&](int l, int ii, float v) {
     __hip_atomic_fetch_add(gg_acc + l * n + ii, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_points_grad_lds_kernel(
 // fp32 summation order.
 __global__ __launch_bounds__(GP_THREADS) void group_points_grad_sorted_kernel(
     int c, int n, int P, const float *__restrict__ grad_out, const int *__restrict__ perm,
-    const int *__restrict__ seg, float *__restrict__ grad_points) {
+    const int *__restrict__ seg, float *__restrict__ grad_points, long long go_bstride) {
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * GP_CH_PER_BLOCK;
   const int nch = min(GP_CH_PER_BLOCK, c - c0);
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_sorted_kernel(
   float acc[GP_CH_PER_BLOCK];
 #pragma unroll
   for (int l = 0; l < GP_CH_PER_BLOCK; ++l) acc[l] = 0.f;
-  const float *g = grad_out + ((size_t)b * c + c0) * P;
+  const float *g = grad_out + (size_t)b * go_bstride + (size_t)c0 * P;
   for (int j = s0; j < s1; ++j) {
     const int p = pb[j];
 #pragma unroll
@@ -235,20 +235,55 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_sorted_kernel(
 
 using namespace pwclo;
 
+// `*_strided` forms: the grouped tensor / its gradient is a channel slice of a larger (B, Ctot, S, K) tensor -- the concatenated
+// input of a shared MLP (P2/pointnet2_modules.py:222,490: cat of the grouped features with the coordinate differences) --
+// so rows of consecutive clouds are `batch_stride` floats apart instead of c * npoints * nsample.  The module path groups
+// straight into / differentiates straight out of that tensor: no torch.cat, no contiguous() copy of the slice.
+static void gp_grad_sorted(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *perm,
+                           const int *seg, float *grad_points, long long go_bstride);
+static void gp_forward(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                       long long out_bstride);
+static void gp_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                    float *grad_points, long long go_bstride);
+
 extern "C" void group_points_grad_sorted_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
                                                         const float *grad_out, const int *perm, const int *seg,
                                                         float *grad_points) {
+  gp_grad_sorted(b, c, n, npoints, nsample, grad_out, perm, seg, grad_points, (long long)c * npoints * nsample);
+}
+extern "C" void group_points_grad_sorted_strided_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                                                const float *grad_out, long long batch_stride,
+                                                                const int *perm, const int *seg, float *grad_points) {
+  gp_grad_sorted(b, c, n, npoints, nsample, grad_out, perm, seg, grad_points, batch_stride);
+}
+extern "C" void group_points_strided_kernel_wrapper(int b, int c, int n, int npoints, int nsample, const float *points,
+                                                    const int *idx, float *out, long long batch_stride) {
+  gp_forward(b, c, n, npoints, nsample, points, idx, out, batch_stride);
+}
+extern "C" void group_points_grad_strided_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
+                                                         const float *grad_out, long long batch_stride, const int *idx,
+                                                         float *grad_points) {
+  gp_grad(b, c, n, npoints, nsample, grad_out, idx, grad_points, batch_stride);
+}
+
+static void gp_grad_sorted(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *perm,
+                           const int *seg, float *grad_points, long long go_bstride) {
   if (b <= 0 || c <= 0 || n <= 0) return;
   const long long P64 = (long long)npoints * nsample;
   PWCLO_REQUIRE(P64 < (1ll << 31) && b <= 65535, "group_points_grad_sorted: npoints*nsample=%lld or b=%d too large",
                 P64, b);
   hipLaunchKernelGGL(group_points_grad_sorted_kernel, dim3(ceil_div(n, GP_THREADS), ceil_div(c, GP_CH_PER_BLOCK), b),
-                     dim3(GP_THREADS), 0, current_stream(), c, n, (int)P64, grad_out, perm, seg, grad_points);
+                     dim3(GP_THREADS), 0, current_stream(), c, n, (int)P64, grad_out, perm, seg, grad_points, go_bstride);
   check_launch("group_points_grad_sorted");
 }
 
 extern "C" void group_points_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
                                             const float *points, const int *idx, float *out) {
+  gp_forward(b, c, n, npoints, nsample, points, idx, out, (long long)c * npoints * nsample);
+}
+
+static void gp_forward(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                       long long out_bstride) {
   if (b <= 0 || c <= 0 || npoints <= 0 || nsample <= 0) return;
   const long long P64 = (long long)npoints * nsample;
   PWCLO_REQUIRE(P64 < (1ll << 31) && b <= 65535, "group_points: npoints*nsample=%lld or b=%d too large",
@@ -291,7 +326,7 @@ extern "C" void group_points_kernel_wrapper(int b, int c, int n, int npoints, in
         attr_set = true;                                                                                        \
       }                                                                                                         \
       hipLaunchKernelGGL((group_points_lds_kernel<TT, NTT>), dim3(gx, gy, b), dim3(TT), lds_bytes,              \
-                         current_stream(), c, n, P, per_wg, points, idx, out);                                  \
+                         current_stream(), c, n, P, per_wg, points, idx, out, out_bstride);                     \
     }
     if (T == 1024 && nt_env) GP_LAUNCH(1024, true)
     else if (T == 1024) GP_LAUNCH(1024, false)
@@ -305,16 +340,21 @@ extern "C" void group_points_kernel_wrapper(int b, int c, int n, int npoints, in
   }
   if (vec)
     hipLaunchKernelGGL(group_points_kernel<true>, dim3(ceil_div(P / 4, GP_THREADS), gy, b),
-                       dim3(GP_THREADS), 0, current_stream(), c, n, P, points, idx, out);
+                       dim3(GP_THREADS), 0, current_stream(), c, n, P, points, idx, out, out_bstride);
   else
     hipLaunchKernelGGL(group_points_kernel<false>, dim3(ceil_div(P, GP_THREADS), gy, b),
-                       dim3(GP_THREADS), 0, current_stream(), c, n, P, points, idx, out);
+                       dim3(GP_THREADS), 0, current_stream(), c, n, P, points, idx, out, out_bstride);
   check_launch("group_points");
 }
 
 extern "C" void group_points_grad_kernel_wrapper(int b, int c, int n, int npoints, int nsample,
                                                  const float *grad_out, const int *idx,
                                                  float *grad_points) {
+  gp_grad(b, c, n, npoints, nsample, grad_out, idx, grad_points, (long long)c * npoints * nsample);
+}
+
+static void gp_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                    float *grad_points, long long go_bstride) {
   if (b <= 0 || c <= 0 || npoints <= 0 || nsample <= 0) return;
   const long long P64 = (long long)npoints * nsample;
   PWCLO_REQUIRE(P64 < (1ll << 31) && b <= 65535,
@@ -340,11 +380,11 @@ extern "C" void group_points_grad_kernel_wrapper(int b, int c, int n, int npoint
       attr_set = true;
     }
     hipLaunchKernelGGL(group_points_grad_lds_kernel, dim3(ceil_div(P, per_split), slices, b), dim3(GG_THREADS),
-                       (size_t)ct * n * 4, current_stream(), c, n, P, ct, per_split, vec4, grad_out, idx, grad_points);
+                       (size_t)ct * n * 4, current_stream(), c, n, P, ct, per_split, vec4, grad_out, idx, grad_points, go_bstride);
     check_launch("group_points_grad");
     return;
   }
   hipLaunchKernelGGL(group_points_grad_kernel, dim3(ceil_div(P, GP_THREADS), ceil_div(c, GP_CH_PER_BLOCK), b),
-                     dim3(GP_THREADS), 0, current_stream(), c, n, P, grad_out, idx, grad_points);
+                     dim3(GP_THREADS), 0, current_stream(), c, n, P, grad_out, idx, grad_points, go_bstride);
   check_launch("group_points_grad");
 }

@@ -224,15 +224,62 @@ def scatter_grad_deterministic(grad_out, idx, n):
     source point), bit-identical from run to run.  The inverse index is a stable torch sort."""
     _float(grad_out, "grad_out"); _int(idx, "idx"); _gpu(grad_out, idx)
     B, C = grad_out.shape[0], grad_out.shape[1]
+    perm, seg = _inverse_index(idx, n)
+    P = perm.shape[1]
+    out = torch.empty((B, C, n), dtype=torch.float32, device=grad_out.device)
+    _lib.call("group_points_grad_sorted_kernel_wrapper", grad_out.device, B, C, n, P, 1, _p(grad_out), _p(perm),
+              _p(seg), _p(out))
+    return out
+
+
+def _inverse_index(idx, n):
+    """perm (B,P) i32 = positions sorted by source point (stable), seg (B,n+1) i32 = segment starts."""
+    B = idx.shape[0]
     flat = idx.reshape(B, -1)
-    P = flat.shape[1]
     order = torch.sort(flat, dim=1, stable=True)
     perm = order.indices.to(torch.int32).contiguous()
     bounds = torch.arange(n + 1, device=idx.device, dtype=flat.dtype).unsqueeze(0).expand(B, -1).contiguous()
     seg = torch.searchsorted(order.values.contiguous(), bounds).to(torch.int32).contiguous()
-    out = torch.empty((B, C, n), dtype=torch.float32, device=grad_out.device)
-    _lib.call("group_points_grad_sorted_kernel_wrapper", grad_out.device, B, C, n, P, 1, _p(grad_out), _p(perm),
-              _p(seg), _p(out))
+    return perm, seg
+
+
+def _slice_ptr(stack, c_off, c):
+    """Address of channel ``c_off`` of cloud 0 of a contiguous (B,Ctot,S,K) tensor + its batch stride in floats."""
+    _float(stack, "stack")
+    if not (0 <= c_off and c_off + c <= stack.shape[1]):
+        raise ValueError("channel slice [%d, %d) outside a tensor of %d channels" % (c_off, c_off + c, stack.shape[1]))
+    P = stack.shape[2] * stack.shape[3]
+    return stack.data_ptr() + 4 * c_off * P, stack.shape[1] * P
+
+
+def group_points_into(points, idx, stack, c_off):
+    """``stack[:, c_off:c_off+C] = group_points(points, idx)`` without the intermediate tensor (the concatenation of
+    P2/pointnet2_modules.py:222-230 done by the grouping kernel itself)."""
+    _float(points, "points"); _int(idx, "idx"); _gpu(points, idx, stack)
+    B, C, N = points.shape
+    S, K = idx.shape[1], idx.shape[2]
+    if tuple(stack.shape[0:1] + stack.shape[2:]) != (B, S, K):
+        raise ValueError("stack %s does not match idx %s" % (tuple(stack.shape), tuple(idx.shape)))
+    ptr, stride = _slice_ptr(stack, c_off, C)
+    _lib.call("group_points_strided_kernel_wrapper", points.device, B, C, N, S, K, _p(points), _p(idx), ptr, stride)
+
+
+def group_points_grad_from(grad_stack, c_off, c, idx, n, deterministic=False, inverse=None):
+    """``group_points_grad(grad_stack[:, c_off:c_off+c].contiguous(), idx, n)`` without the copy.  ``deterministic``: the
+    atomics-free kernel (``inverse`` = a cached ``_inverse_index(idx, n)``)."""
+    _int(idx, "idx"); _gpu(grad_stack, idx)
+    B, S, K = idx.shape
+    if tuple(grad_stack.shape[0:1] + grad_stack.shape[2:]) != (B, S, K):
+        raise ValueError("grad_stack %s does not match idx %s" % (tuple(grad_stack.shape), tuple(idx.shape)))
+    ptr, stride = _slice_ptr(grad_stack, c_off, c)
+    if deterministic:
+        perm, seg = inverse if inverse is not None else _inverse_index(idx, n)
+        out = torch.empty((B, c, n), dtype=torch.float32, device=grad_stack.device)
+        _lib.call("group_points_grad_sorted_strided_kernel_wrapper", grad_stack.device, B, c, n, S * K, 1, ptr, stride,
+                  _p(perm), _p(seg), _p(out))
+        return out
+    out = torch.zeros((B, c, n), dtype=torch.float32, device=grad_stack.device)
+    _lib.call("group_points_grad_strided_kernel_wrapper", grad_stack.device, B, c, n, S, K, ptr, stride, _p(idx), _p(out))
     return out
 
 

@@ -154,11 +154,9 @@ class PointnetSAModulePWCLONet(nn.Module):
         _, idx_q = pt_utils.knn_point(self.nsample, xyz, new_xyz)
         grouped_xyz = pointnet2_utils.grouping_operation(xyz_flipped, idx_q)
         xyz_diff = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
-        if features is not None:
-            grouped_features = pointnet2_utils.grouping_operation(features, idx_q)
-            new_features = torch.cat((xyz_diff, grouped_features), dim=1)
-        else:
-            new_features = torch.cat((xyz_diff, grouped_xyz), dim=1)
+        # cat((xyz_diff, grouped features)) with the grouping kernel writing its channel slice of the result directly
+        new_features = pointnet2_utils.group_concat(
+            idx_q, ("t", xyz_diff), ("g", features if features is not None else xyz_flipped))
         new_features = pt_utils.shared_mlp_max(self.mlp_module, new_features)  # mlp, then max_pool2d(kernel=[1,K])
         return new_xyz, new_features
 
@@ -184,11 +182,12 @@ class PointnetFPModulePWCLONet(nn.Module):
                 features1: torch.Tensor) -> torch.Tensor:
         if self.knn:
             _, idx_q = pt_utils.knn_point(self.nsample, xyz1, xyz2)
-            new_features = pointnet2_utils.grouping_operation(features1, idx_q)
             grouped_xyz = pointnet2_utils.grouping_operation(xyz1.transpose(1, 2).contiguous(), idx_q)
             xyz_diff = grouped_xyz - xyz2.transpose(1, 2).unsqueeze(-1)
             if self.use_xyz:
-                new_features = torch.cat((new_features, xyz_diff), dim=1)
+                new_features = pointnet2_utils.group_concat(idx_q, ("g", features1), ("t", xyz_diff))
+            else:
+                new_features = pointnet2_utils.grouping_operation(features1, idx_q)
         else:
             new_features = self.grouper(xyz1, xyz2, features1)
         new_features = pt_utils.shared_mlp_max(self.mlp, new_features)

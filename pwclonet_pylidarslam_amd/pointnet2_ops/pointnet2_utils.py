@@ -170,6 +170,56 @@ class GroupingOperation(Function):
 grouping_operation = GroupingOperation.apply
 
 
+class GroupConcat(Function):
+    """``torch.cat([part_0, part_1, ...], dim=1)`` of a shared MLP's input where some parts are
+    ``grouping_operation(features, idx)``: those are grouped by the kernel straight into their channel slice of the
+    result, and in backward their gradient is scattered straight out of the slice of the incoming gradient (the
+    reference writes the grouped tensor and copies it again in ``torch.cat``: P2/pointnet2_modules.py:222-230, 490-500,
+    PW/costvolume.py:134, 172).  Same values, two copies of the grouped tensor fewer each way."""
+
+    @staticmethod
+    def forward(ctx, idx, kinds, *tensors):
+        B, S, K = idx.shape
+        chans = [t.shape[1] for t in tensors]
+        ref = tensors[0]
+        out = torch.empty((B, sum(chans), S, K), dtype=ref.dtype, device=ref.device)
+        off = 0
+        for kind, t, c in zip(kinds, tensors, chans):
+            if kind == "g":
+                _ext.group_points_into(t.contiguous(), idx, out, off)
+            else:
+                out[:, off:off + c].copy_(t)          # dense part (may be an expanded view: one strided copy)
+            off += c
+        ctx.save_for_backward(idx)
+        ctx.kinds, ctx.chans = kinds, chans
+        ctx.ns = [t.shape[2] for t in tensors]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        g = grad_out.contiguous()
+        det = deterministic_grads()
+        inverse = {}
+        grads, off = [], 0
+        for i, (kind, c, n) in enumerate(zip(ctx.kinds, ctx.chans, ctx.ns)):
+            if not ctx.needs_input_grad[2 + i]:
+                grads.append(None)
+            elif kind == "g":
+                if det and n not in inverse:
+                    inverse[n] = _ext._inverse_index(idx, n)
+                grads.append(_ext.group_points_grad_from(g, off, c, idx, n, deterministic=det, inverse=inverse.get(n)))
+            else:
+                grads.append(g[:, off:off + c])
+            off += c
+        return (None, None) + tuple(grads)
+
+
+def group_concat(idx, *parts):
+    """parts: ``("g", features (B,C,N))`` = grouped by idx, or ``("t", tensor (B,C,S,K))``; -> (B, sum C, S, K)."""
+    return GroupConcat.apply(idx, tuple(k for k, _ in parts), *[t for _, t in parts])
+
+
 class BallQuery(Function):
     @staticmethod
     def forward(ctx, radius, nsample, xyz, new_xyz):

@@ -44,10 +44,10 @@ class CostVolume(nn.Module):
         # first aggregate: frame-2 neighbours of every (warped) frame-1 point
         _, idx_q = pt_utils.knn_point(kq, f2_xyz_t, warped_xyz_t)
         q_xyz = pointutils.grouping_operation(f2_xyz.contiguous(), idx_q)
-        q_pts = pointutils.grouping_operation(f2_points.contiguous(), idx_q)
         geo = _geometry(warped_xyz, q_xyz)
         p_pts = warped_points.unsqueeze(3).expand(-1, -1, -1, kq)
-        feat = self.mlp_convs(torch.cat((geo, p_pts, q_pts), dim=1))
+        # cat((geo, p_pts, grouped frame-2 features)): the grouping kernel writes its slice of the result directly
+        feat = self.mlp_convs(pointutils.group_concat(idx_q, ("t", geo), ("t", p_pts), ("g", f2_points)))
         enc = self.mlp_conv_xyz_1(geo)
         # softmax over the neighbours + weighted sum (costvolume.py:139-141) as one kernel each way on the GPU
         first = softmax_weighted_sum(self.mlp2_convs(torch.cat((enc, feat), dim=1)), feat)

@@ -539,6 +539,43 @@ def test_deterministic_scatter_grad(cuda, b, c, n, s, k):
         PU.deterministic_grads(False)
 
 
+@pytest.mark.parametrize("b,c,n,s,k", [(2, 16, 500, 300, 8), (3, 67, 1024, 2048, 4), (1, 3, 64, 257, 3), (2, 3, 8192, 2048, 32),
+                                       (2, 128, 5000, 64, 16)])
+def test_group_concat_equals_cat_of_grouped(cuda, b, c, n, s, k):
+    """The concatenated input of a shared MLP (P2/pointnet2_modules.py:222-230, PW/costvolume.py:134) built with the
+    grouping kernel writing its channel slice directly: bit-identical to ``torch.cat`` of ``grouping_operation`` forward,
+    and its backward (atomic and atomics-free form) equals the oracle's group_points_grad of the gradient's slice."""
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pointnet2_utils as PU
+    gen = torch.Generator().manual_seed(b * 77 + n + k)
+    idx = torch.randint(0, n, (b, s, k), generator=gen, dtype=torch.int32)
+    feat = torch.randn(b, c, n, generator=gen)
+    other = torch.randn(b, 5, n, generator=gen)
+    dense = torch.randn(b, 3, s, k, generator=gen)
+    centre = torch.randn(b, 7, s, generator=gen)
+    go = torch.randn(b, 3 + c + 7 + 5, s, k, generator=gen)
+    want = torch.cat((dense, O.group_points(feat, idx), centre.unsqueeze(3).expand(-1, -1, -1, k),
+                      O.group_points(other, idx)), dim=1)
+    for det in (False, True):
+        PU.deterministic_grads(det)
+        try:
+            f, o, d, ce = (t.to(cuda).requires_grad_(True) for t in (feat, other, dense, centre))
+            got = PU.group_concat(g(idx, cuda), ("t", d), ("g", f), ("t", ce.unsqueeze(3).expand(-1, -1, -1, k)), ("g", o))
+            assert torch.equal(got.cpu(), want)
+            got.backward(g(go, cuda))
+            torch.testing.assert_close(f.grad.cpu(), O.group_points_grad(go[:, 3:3 + c].contiguous(), idx, n),
+                                       rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(o.grad.cpu(), O.group_points_grad(go[:, 10 + c:].contiguous(), idx, n),
+                                       rtol=1e-5, atol=1e-5)
+            assert torch.equal(d.grad.cpu(), go[:, :3])
+            torch.testing.assert_close(ce.grad.cpu(), go[:, 3 + c:10 + c].sum(3), rtol=1e-5, atol=1e-5)
+            if det:
+                assert torch.equal(f.grad, E.scatter_grad_deterministic(g(go[:, 3:3 + c].contiguous(), cuda), g(idx, cuda), n))
+        finally:
+            PU.deterministic_grads(False)
+    with pytest.raises(ValueError):
+        E.group_points_into(g(feat, cuda), g(idx, cuda), torch.empty(b, c, s, k, device=cuda), 1)
+
+
 @pytest.mark.parametrize("shape", [(4, 8, 300, 7), (8, 16, 2048, 32), (2, 64, 1, 5), (3, 5, 1000), (32, 128, 64, 8)])
 @pytest.mark.parametrize("affine,relu", [(True, False), (False, False), (True, True)])
 def test_batchnorm_train_kernels(cuda, shape, affine, relu):
