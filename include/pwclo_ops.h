@@ -418,6 +418,24 @@ void conv1x1_bnrelu_forward_kernel_wrapper(int b, int cin, int cout, int p, cons
 void conv1x1_bnrelu_wgrad_kernel_wrapper(int b, int cin, int cout, int p, const float *dy, const float *x,
                                          const float *in_mean, const float *in_invstd, const float *in_gamma,
                                          const float *in_beta, float *dw, void *workspace);
+/* Training mode, conv -> BatchNorm of the SAME block (pytorch_utils.py:114-167): y = W a (a = x, or the transformed
+ * input of conv1x1_bnrelu_forward when in_mean != NULL) AND the batch statistics of y for the BatchNorm that follows --
+ * save_mean, save_invstd (cout), the momentum update of running_mean / running_var (nullable, unbiased variance) --
+ * from per-workgroup fp64 partial sums the convolution's epilogue leaves: the statistics pass of
+ * batchnorm_train_forward_kernel_wrapper(y = NULL) without reading y again.  workspace: conv1x1_stats_workspace_bytes(). */
+long long conv1x1_stats_workspace_bytes(int b, int cin, int cout, int p);
+void conv1x1_forward_bnstats_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
+                                            const float *in_mean, const float *in_invstd, const float *in_gamma,
+                                            const float *in_beta, float *y, float eps, float momentum,
+                                            float *running_mean, float *running_var, float *save_mean,
+                                            float *save_invstd, void *workspace);
+/* The apply passes of batchnorm_train_forward / batchnorm_train_relu_maxk_forward alone, for statistics obtained that
+ * way: y = [relu]((x - mean) * invstd * gamma + beta); pooled / arg / xsel as documented above. */
+void batchnorm_train_apply_kernel_wrapper(int b, int c, int l, const float *x, const float *gamma, const float *beta,
+                                          const float *mean, const float *invstd, float *y, int relu);
+void batchnorm_train_relu_maxk_apply_kernel_wrapper(int b, int c, int s, int k, const float *x, const float *gamma,
+                                                    const float *beta, const float *mean, const float *invstd,
+                                                    float *pooled, unsigned char *arg, float *xsel);
 /* The same followed by the stack's max over the k neighbours (P2/pointnet2_modules.py: SharedMLP then .max(dim=3) /
  * max_pool2d(kernel=[1, nsample])): x (b, cin, s, k), pooled (b, cout, s) = max_k act(conv(x) * scale + shift); the
  * (b, cout, s, k) activation is not written.  k in {4, 8, 16, 32}. */

@@ -63,19 +63,24 @@ def _workspace(c, device):
 
 class _BatchNormTrain(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, given_mean=None, given_invstd=None):
         if not x.is_cuda:
             raise RuntimeError("CPU not supported")
         x = x.contiguous()
         B, C = x.shape[0], x.shape[1]
         L = x.numel() // (B * C)
         y = torch.empty_like(x)
-        save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
-        save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
-        ws = _workspace(C, x.device)
         p = lambda t: t.data_ptr() if t is not None else 0
-        _lib.call("batchnorm_train_forward_kernel_wrapper", x.device, B, C, L, p(x), p(weight), p(bias), float(eps),
-                  float(momentum), p(running_mean), p(running_var), p(y), p(save_mean), p(save_invstd), p(ws), int(relu))
+        if given_mean is not None:       # the producing convolution's epilogue already has the statistics (conv1x1_stats)
+            save_mean, save_invstd = given_mean, given_invstd
+            _lib.call("batchnorm_train_apply_kernel_wrapper", x.device, B, C, L, p(x), p(weight), p(bias), p(save_mean),
+                      p(save_invstd), p(y), int(relu))
+        else:
+            save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+            save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+            ws = _workspace(C, x.device)
+            _lib.call("batchnorm_train_forward_kernel_wrapper", x.device, B, C, L, p(x), p(weight), p(bias), float(eps),
+                      float(momentum), p(running_mean), p(running_var), p(y), p(save_mean), p(save_invstd), p(ws), int(relu))
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
         ctx.relu = bool(relu)
         return y
@@ -95,7 +100,7 @@ class _BatchNormTrain(Function):
         _lib.call("batchnorm_train_backward_kernel_wrapper", x.device, B, C, L, p(x), p(dy), p(weight), p(bias),
                   p(save_mean), p(save_invstd), p(dx), p(dgamma), p(dbeta), p(ws), int(ctx.relu))
         return (dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), None, None, None,
-                None, None)
+                None, None, None, None)
 
 
 def supported(x, bn):
@@ -105,9 +110,13 @@ def supported(x, bn):
             and (not bn.track_running_stats or bn.running_mean is not None))
 
 
-def batch_norm_train(x, bn, relu=False):
+def batch_norm_train(x, bn, relu=False, stats=None):
     """Training-mode forward of the ``torch.nn.BatchNorm*`` module ``bn`` on ``x`` (updates its running statistics
-    and ``num_batches_tracked`` like ``bn(x)`` does); ``relu=True`` also applies the stack's ReLU in the same pass."""
+    and ``num_batches_tracked`` like ``bn(x)`` does); ``relu=True`` also applies the stack's ReLU in the same pass.
+    ``stats = (mean, invstd)``: the batch statistics of ``x`` as ``conv1x1.conv1x1_stats`` returned them (that call has
+    already updated the running statistics and the counter): only the apply pass runs."""
+    if stats is not None:
+        return _BatchNormTrain.apply(x, bn.weight, bn.bias, None, None, bn.momentum, bn.eps, relu, stats[0], stats[1])
     count_batch(bn)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
@@ -122,19 +131,24 @@ class _BatchNormReluMaxK(Function):
     the forward keeps the arg-max and the selected inputs, the backward rebuilds the sparse gradient from them."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, given_mean=None, given_invstd=None):
         x = x.contiguous()
         B, C, S, K = x.shape
         pooled = torch.empty((B, C, S), dtype=torch.float32, device=x.device)
         arg = torch.empty((B, C, S), dtype=torch.uint8, device=x.device)
         xsel = torch.empty((B, C, S), dtype=torch.float32, device=x.device)
-        save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
-        save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
-        ws = _workspace(C, x.device)
         p = lambda t: t.data_ptr() if t is not None else 0
-        _lib.call("batchnorm_train_relu_maxk_forward_kernel_wrapper", x.device, B, C, S, K, p(x), p(weight), p(bias),
-                  float(eps), float(momentum), p(running_mean), p(running_var), p(pooled), p(arg), p(xsel), p(save_mean),
-                  p(save_invstd), p(ws))
+        if given_mean is not None:
+            save_mean, save_invstd = given_mean, given_invstd
+            _lib.call("batchnorm_train_relu_maxk_apply_kernel_wrapper", x.device, B, C, S, K, p(x), p(weight), p(bias),
+                      p(save_mean), p(save_invstd), p(pooled), p(arg), p(xsel))
+        else:
+            save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+            save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+            ws = _workspace(C, x.device)
+            _lib.call("batchnorm_train_relu_maxk_forward_kernel_wrapper", x.device, B, C, S, K, p(x), p(weight), p(bias),
+                      float(eps), float(momentum), p(running_mean), p(running_var), p(pooled), p(arg), p(xsel),
+                      p(save_mean), p(save_invstd), p(ws))
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd, arg, xsel)
         return pooled
 
@@ -152,16 +166,18 @@ class _BatchNormReluMaxK(Function):
         _lib.call("batchnorm_train_relu_maxk_backward_kernel_wrapper", x.device, B, C, S, K, p(x), p(dpool), p(arg),
                   p(xsel), p(weight), p(bias), p(save_mean), p(save_invstd), p(dx), p(dgamma), p(dbeta), p(ws))
         return (dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), None, None, None,
-                None)
+                None, None, None)
 
 
 def supported_maxk(x, bn):
     return supported(x, bn) and x.dim() == 4 and x.shape[3] in (4, 8, 16, 32)
 
 
-def batch_norm_train_relu_max(x, bn):
+def batch_norm_train_relu_max(x, bn, stats=None):
     """``relu(bn(x)).max(dim=3)[0]`` for the training-mode module ``bn`` and x (B, C, S, K): one statistics pass and one
-    pooled pass, nothing of shape (B, C, S, K) written."""
+    pooled pass, nothing of shape (B, C, S, K) written.  ``stats``: see ``batch_norm_train``."""
+    if stats is not None:
+        return _BatchNormReluMaxK.apply(x, bn.weight, bn.bias, None, None, bn.momentum, bn.eps, stats[0], stats[1])
     count_batch(bn)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None

@@ -76,6 +76,24 @@ def _forward(x, w2d, transposed, cin, cout):
     return y
 
 
+def _conv_backward(ctx, dy):
+    x, weight = ctx.saved_tensors
+    dy = _aligned(dy)
+    w = _aligned(weight.detach())
+    B, cin, cout, P = _shape(x, w)
+    dx = dw = None
+    if ctx.needs_input_grad[0]:
+        dx = _forward(dy, w, True, cout, cin)                     # dX = W^T dY: same kernel, transposed view
+    if ctx.needs_input_grad[1]:
+        nbytes = _lib.load().conv1x1_wgrad_workspace_bytes(B, cin, cout, P)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+        dw = torch.empty_like(w)
+        _lib.call("conv1x1_wgrad_kernel_wrapper", x.device, B, cin, cout, P, dy.data_ptr(), x.data_ptr(),
+                  dw.data_ptr(), ws.data_ptr())
+        dw = dw.view_as(weight)
+    return dx, dw
+
+
 class _Conv1x1(Function):
     @staticmethod
     def forward(ctx, x, weight):
@@ -88,26 +106,72 @@ class _Conv1x1(Function):
     @staticmethod
     @once_differentiable            # raw kernels: a second differentiation raises instead of returning constants
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dy = _aligned(dy)
-        w = _aligned(weight.detach())
-        B, cin, cout, P = _shape(x, w)
-        dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = _forward(dy, w, True, cout, cin)                     # dX = W^T dY: same kernel, transposed view
-        if ctx.needs_input_grad[1]:
-            nbytes = _lib.load().conv1x1_wgrad_workspace_bytes(B, cin, cout, P)
-            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
-            dw = torch.empty_like(w)
-            _lib.call("conv1x1_wgrad_kernel_wrapper", x.device, B, cin, cout, P, dy.data_ptr(), x.data_ptr(),
-                      dw.data_ptr(), ws.data_ptr())
-            dw = dw.view_as(weight)
-        return dx, dw
+        return _conv_backward(ctx, dy)
 
 
 def conv1x1(x, weight):
     """``F.conv{1,2,3}d(x, weight)`` for a size-1 kernel: x (B, Cin, *), weight (Cout, Cin, 1[, 1[, 1]])."""
     return _Conv1x1.apply(x, weight)
+
+
+def _forward_stats(x, w, cin, cout, in_tf, rm, rv, momentum, eps):
+    """The convolution (optionally with the previous BatchNorm + ReLU applied on load, ``in_tf = (mean, invstd, gamma,
+    beta)``) that also leaves the batch statistics of its OUTPUT: (y, mean, invstd) and the running-statistics update."""
+    B = x.shape[0]
+    P = x.numel() // (B * cin)
+    y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    mean = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    nbytes = _lib.load().conv1x1_stats_workspace_bytes(B, cin, cout, P)
+    ws = torch.empty((nbytes // 8,), dtype=torch.float64, device=x.device)
+    p = lambda t: t.data_ptr() if t is not None else 0
+    tf = in_tf if in_tf is not None else (None, None, None, None)
+    _lib.call("conv1x1_forward_bnstats_kernel_wrapper", x.device, B, cin, cout, P, p(x), p(w), p(tf[0]), p(tf[1]), p(tf[2]),
+              p(tf[3]), p(y), float(eps), float(momentum), p(rm), p(rv), p(mean), p(invstd), p(ws))
+    return y, mean, invstd
+
+
+class _Conv1x1Stats(Function):
+    """``_Conv1x1`` whose forward also returns the batch statistics (mean, 1/sqrt(var + eps)) of its output, summed in the
+    convolution's epilogue, for the training-mode BatchNorm that follows it (and updates that layer's running
+    statistics).  The statistics are returned as constants: the consumer's backward (batchnorm / _BNReluConv) is the full
+    BatchNorm backward, which already accounts for their dependence on the output."""
+
+    @staticmethod
+    def forward(ctx, x, weight, running_mean, running_var, momentum, eps):
+        x = _aligned(x)
+        w = _aligned(weight.detach())
+        B, cin, cout, P = _shape(x, w)
+        ctx.save_for_backward(x, weight)
+        y, mean, invstd = _forward_stats(x, w, cin, cout, None, running_mean, running_var, momentum, eps)
+        ctx.mark_non_differentiable(mean, invstd)
+        ctx.set_materialize_grads(False)          # no zero-filled "gradients" of the two statistics vectors in backward
+        return y, mean, invstd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _dmean, _dinvstd):
+        if dy is None:
+            return None, None, None, None, None, None
+        dx, dw = _conv_backward(ctx, dy)
+        return dx, dw, None, None, None, None
+
+
+def _bn_buffers(bn):
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return rm, rv
+
+
+def conv1x1_stats(x, conv, bn):
+    """``conv(x)`` plus the batch statistics of the result for the training-mode module ``bn`` that follows ``conv`` in
+    its block: -> (y, (mean, invstd)); ``bn``'s running statistics and counter are updated as ``bn(y)`` would."""
+    from . import batchnorm as hb
+    hb.count_batch(bn)
+    rm, rv = _bn_buffers(bn)
+    y, mean, invstd = _Conv1x1Stats.apply(x, conv.weight, rm, rv, bn.momentum, bn.eps)
+    touch_running_stats(rm, rv)
+    return y, (mean, invstd)
 
 
 def _folded(bn):
@@ -177,27 +241,41 @@ class _BNReluConv(Function):
     recomputed from ``x`` like in batchnorm._BatchNormTrain)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, weight):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, weight, given_mean=None, given_invstd=None,
+                out_stats=None):
+        """``given_*``: the batch statistics of x from the producing convolution's epilogue (no statistics pass here).
+        ``out_stats = (running_mean, running_var, momentum, eps)`` of the BatchNorm FOLLOWING this convolution: the
+        forward then returns (y, mean_y, invstd_y) like ``_Conv1x1Stats``."""
         from . import batchnorm as hb
         x = _aligned(x)
         w = _aligned(weight.detach())
         B, cin, cout, P = _shape(x, w)
-        mean = torch.empty((cin,), dtype=torch.float32, device=x.device)
-        invstd = torch.empty((cin,), dtype=torch.float32, device=x.device)
-        ws = hb._workspace(cin, x.device)
         p = lambda t: t.data_ptr() if t is not None else 0
-        _lib.call("batchnorm_train_forward_kernel_wrapper", x.device, B, cin, P, p(x), p(gamma), p(beta), float(eps),
-                  float(momentum), p(running_mean), p(running_var), 0, p(mean), p(invstd), p(ws), 1)
+        if given_mean is not None:
+            mean, invstd = given_mean, given_invstd
+        else:
+            mean = torch.empty((cin,), dtype=torch.float32, device=x.device)
+            invstd = torch.empty((cin,), dtype=torch.float32, device=x.device)
+            ws = hb._workspace(cin, x.device)
+            _lib.call("batchnorm_train_forward_kernel_wrapper", x.device, B, cin, P, p(x), p(gamma), p(beta), float(eps),
+                      float(momentum), p(running_mean), p(running_var), 0, p(mean), p(invstd), p(ws), 1)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, weight)
+        if out_stats is not None:
+            y, mean_y, invstd_y = _forward_stats(x, w, cin, cout, (mean, invstd, gamma, beta), *out_stats)
+            ctx.mark_non_differentiable(mean_y, invstd_y)
+            ctx.set_materialize_grads(False)
+            return y, mean_y, invstd_y
         y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
         _lib.call("conv1x1_bnrelu_forward_kernel_wrapper", x.device, B, cin, cout, P, p(x), p(w), p(mean), p(invstd),
                   p(gamma), p(beta), p(y))
-        ctx.save_for_backward(x, gamma, beta, mean, invstd, weight)
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_dstats):
         from . import batchnorm as hb
+        if dy is None:
+            return (None,) * 11
         x, gamma, beta, mean, invstd, weight = ctx.saved_tensors
         dy = _aligned(dy)
         w = _aligned(weight.detach())
@@ -222,16 +300,30 @@ class _BNReluConv(Function):
                       p(mean), p(invstd), p(dx), p(dgamma), p(dbeta), p(ws2), 1)
             if gamma is None:
                 dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None, dw
+        return dx, dgamma, dbeta, None, None, None, None, dw, None, None, None
 
 
-def bn_relu_conv(x, bn, conv):
+def bn_relu_conv(x, bn, conv, stats=None, next_bn=None):
     """``conv(relu(bn(x)))`` for a training-mode ``torch.nn.BatchNorm*`` module ``bn`` (updates its running statistics and
-    ``num_batches_tracked`` like ``bn(x)``) and a bias-free pointwise ``conv`` that ``supported(x, conv)`` accepts."""
+    ``num_batches_tracked`` like ``bn(x)``) and a bias-free pointwise ``conv`` that ``supported(x, conv)`` accepts.
+    ``stats``: (mean, invstd) of ``x`` when the convolution that produced ``x`` already summed them (``conv1x1_stats`` /
+    this function with ``next_bn``; the running statistics were updated there).  ``next_bn``: the training-mode BatchNorm
+    that follows ``conv``; the result is then (y, (mean_y, invstd_y)) and ``next_bn``'s buffers are updated."""
     from . import batchnorm as hb
-    hb.count_batch(bn)
-    rm = bn.running_mean if bn.track_running_stats else None
-    rv = bn.running_var if bn.track_running_stats else None
-    y = _BNReluConv.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, conv.weight)
+    if stats is None:
+        hb.count_batch(bn)
+        rm, rv = _bn_buffers(bn)
+    else:
+        rm = rv = None
+    given = stats if stats is not None else (None, None)
+    out_stats = None
+    if next_bn is not None:
+        hb.count_batch(next_bn)
+        nrm, nrv = _bn_buffers(next_bn)
+        out_stats = (nrm, nrv, next_bn.momentum, next_bn.eps)
+    out = _BNReluConv.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, conv.weight, given[0], given[1], out_stats)
     touch_running_stats(rm, rv)
-    return y
+    if next_bn is not None:
+        touch_running_stats(nrm, nrv)
+        return out[0], (out[1], out[2])
+    return out

@@ -295,6 +295,14 @@ static int bn_splits(int c, long long M, long long *per_split) {
   return (int)((M + ps - 1) / ps);
 }
 
+// for conv1x1.hip: the statistics of a convolution's output from the partial sums its epilogue left
+void bn_forward_finish_launch(int c, int nsplit, long long M, float eps, float momentum, const double *partial,
+                              float *running_mean, float *running_var, float *save_mean, float *save_invstd) {
+  hipLaunchKernelGGL(bn_forward_finish_kernel, dim3(ceil_div(c, 4)), dim3(256), 0, current_stream(), c, nsplit, M, eps,
+                     momentum, partial, running_mean, running_var, save_mean, save_invstd);
+  check_launch("bn_forward_finish");
+}
+
 }  // namespace pwclo
 
 using namespace pwclo;
@@ -377,6 +385,25 @@ extern "C" void batchnorm_train_backward_kernel_wrapper(int b, int c, int l, con
   check_launch("batchnorm_train_backward");
 }
 
+// y = [relu]((x - mean) * invstd * gamma + beta) with GIVEN batch statistics (those conv1x1_forward_bnstats_kernel_wrapper
+// left): the apply pass of batchnorm_train_forward_kernel_wrapper alone.
+extern "C" void batchnorm_train_apply_kernel_wrapper(int b, int c, int l, const float *x, const float *gamma,
+                                                     const float *beta, const float *mean, const float *invstd, float *y,
+                                                     int relu) {
+  if (b <= 0 || c <= 0 || l <= 0) return;
+  PWCLO_REQUIRE(b <= 65535 && c <= 65535, "batchnorm_train_apply: b=%d c=%d exceed the grid limits", b, c);
+  const bool vec = (l % 4 == 0);
+  PWCLO_REQUIRE(!vec || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0),
+                "batchnorm_train_apply: x and y must be 16-byte aligned%s", "");
+  const float *none = nullptr;
+  hipStream_t st = current_stream();
+  if (relu)
+    bn_launch_apply<0, true>(vec, b, c, l, 0.f, x, none, gamma, beta, mean, invstd, none, none, y, st);
+  else
+    bn_launch_apply<0, false>(vec, b, c, l, 0.f, x, none, gamma, beta, mean, invstd, none, none, y, st);
+  check_launch("batchnorm_train_apply");
+}
+
 // ---- BatchNorm -> ReLU -> max over K (tail of the grouped stacks) ------------------------------------------------
 #define PWCLO_BN_MAXK_DISPATCH(k, CALL) \
   switch (k) {                          \
@@ -416,6 +443,26 @@ extern "C" void batchnorm_train_relu_maxk_forward_kernel_wrapper(int b, int c, i
   PWCLO_BN_MAXK_DISPATCH(k, PWCLO_CALL)
 #undef PWCLO_CALL
   check_launch("batchnorm_train_relu_maxk_forward");
+}
+
+// The pooled pass alone, with GIVEN batch statistics (see batchnorm_train_apply_kernel_wrapper).
+extern "C" void batchnorm_train_relu_maxk_apply_kernel_wrapper(int b, int c, int s, int k, const float *x,
+                                                               const float *gamma, const float *beta, const float *mean,
+                                                               const float *invstd, float *pooled, unsigned char *arg,
+                                                               float *xsel) {
+  if (b <= 0 || c <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(k == 4 || k == 8 || k == 16 || k == 32, "batchnorm_train_relu_maxk_apply: k=%d not in {4,8,16,32}", k);
+  PWCLO_REQUIRE(b <= 65535 && c <= 65535, "batchnorm_train_relu_maxk_apply: b=%d c=%d exceed the grid limits", b, c);
+  PWCLO_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "batchnorm_train_relu_maxk_apply: x must be 16-byte aligned%s", "");
+  const int l = s * k;
+  hipStream_t st = current_stream();
+  const dim3 grid(ceil_div(l / 4, BN_THREADS), c, b);
+#define PWCLO_CALL(KK)                                                                                              \
+  hipLaunchKernelGGL((bn_apply_relu_maxk_kernel<KK>), grid, dim3(BN_THREADS), 0, st, c, s, x, gamma, beta, mean, invstd, \
+                     pooled, arg, xsel)
+  PWCLO_BN_MAXK_DISPATCH(k, PWCLO_CALL)
+#undef PWCLO_CALL
+  check_launch("batchnorm_train_relu_maxk_apply");
 }
 
 extern "C" void batchnorm_train_relu_maxk_backward_kernel_wrapper(int b, int c, int s, int k, const float *x,

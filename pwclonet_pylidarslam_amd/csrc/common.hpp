@@ -14,6 +14,10 @@ constexpr int WAVE = 64;
 hipStream_t current_stream();
 void set_error(int code, const char *fmt, ...);
 bool check_launch(const char *what);  // hipGetLastError() -> sticky error; true when OK
+// batchnorm.hip: save_mean / save_invstd / running statistics of c channels from fp64 partial sums
+// partial[(ch * nsplit + s) * 2 + {sum, sum of squares}] over M elements per channel (conv1x1.hip's statistics epilogue)
+void bn_forward_finish_launch(int c, int nsplit, long long M, float eps, float momentum, const double *partial,
+                              float *running_mean, float *running_var, float *save_mean, float *save_invstd);
 // Device view of the library's pinned error word (state.hip): a kernel stores a PWCLO_E* code there with a
 // system-scope atomic; pwclo_last_error() picks it up.  nullptr (and a sticky error) if it cannot be allocated.
 unsigned *device_error_word();

@@ -26,14 +26,21 @@ constexpr int CONV_THREADS = 512;            // 8 waves: 2 per SIMD
 constexpr int CONV_WAVES = CONV_THREADS / WAVE;
 constexpr int CONV_MAX_NBO = 8;              // 16-channel output blocks per workgroup (128 accumulator VGPRs)
 constexpr int CONV_AHEAD = 4;               // channel blocks in flight per wave (forward / input gradient)
+constexpr int CONV_STAT_TILES = 32;        // tiles a lane adds in fp32 before its sums go to the fp64 slots
 constexpr int WGRAD_MAXV = 7;                // float4 per thread of one staged weight-gradient chunk
 
 // y[b][co][p] = sum_ci W(co, ci) x[b][ci][p], W(co, ci) = w[co * w_ld_o + ci * w_ld_i]  (strides: the same kernel
 // computes the input gradient with the transposed view).  P % 4 == 0, rows 16-byte aligned.  Epilogue (forward only):
 // ep_scale / ep_shift (per output channel, nullable) and ep_relu; ep_pool = K > 0 writes max over each row of K pixels.
 // grid (x = persistent tile workers, y = groups of NBO output blocks); dynamic LDS = NBO * nbi KiB.
-template <int NBO>
-__global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kernel(int B, int Cin, int Cout, int P, int nbi,
+// STATS (training forward): the kernel also leaves, per output channel, the partial sums (sum y, sum y^2) of everything
+// THIS workgroup wrote, in fp64, at stats_partial[(co * gridDim.x + blockIdx.x) * 2 + {0, 1}] -- the layout
+// bn_forward_finish_kernel folds -- so the BatchNorm that follows the convolution (pytorch_utils.py:114-167: conv -> bn ->
+// relu) needs no statistics pass over y.  Per lane the two pixels of a tile are added in fp32 for at most CONV_STAT_TILES
+// tiles (64 values), then reduced over the 16 lanes of a row (DPP) and added to the wave's own fp64 slot in LDS by one
+// lane; the 8 slots are summed in wave order at the end: deterministic, and within ~1e-6 of the fp64 pass it replaces.
+template <int NBO, bool STATS>
+__global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 1 : 2)) void conv1x1_kernel(int B, int Cin, int Cout, int P, int nbi,
                                                               long long w_ld_o, long long w_ld_i,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y,
@@ -42,7 +49,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
                                                               const float *__restrict__ in_mean,
                                                               const float *__restrict__ in_invstd,
                                                               const float *__restrict__ in_gamma,
-                                                              const float *__restrict__ in_beta) {
+                                                              const float *__restrict__ in_beta,
+                                                              double *__restrict__ stats_partial) {
   extern __shared__ float4 conv_w[];         // [NBO][nbi][64 lanes] : the 4 k-steps of one (o, m) tile per lane
   const int ob0 = blockIdx.y * NBO;
   {
@@ -77,6 +85,10 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
     // is applied on the fly, a = max(((x - mean) * invstd) * gamma + beta, 0) -- the expression of bn_apply_kernel, so
     // the normalised activation is never written; per input channel (mean, invstd, gamma, beta), zeros for padding
     float4 *conv_in = conv_w + NBO * nbi * WAVE;
+    if (STATS) {
+      double *slots = reinterpret_cast<double *>(conv_in + nbi * 16);       // [8 waves][NBO * 16 channels][2]
+      for (int e = threadIdx.x; e < CONV_WAVES * NBO * 16 * 2; e += CONV_THREADS) slots[e] = 0.0;
+    }
     if (in_mean != nullptr)
       for (int c = threadIdx.x; c < nbi * 16; c += CONV_THREADS)
         conv_in[c] = c < Cin ? make_float4(in_mean[c], in_invstd[c], in_gamma ? in_gamma[c] : 1.f, in_beta ? in_beta[c] : 0.f)
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
   const long long tiles = (long long)B * tpb;
   const long long tstep = (long long)gridDim.x * CONV_WAVES;
   const long long t0 = (long long)blockIdx.x * CONV_WAVES + wave;
-  if (t0 >= tiles) return;
+  if (!STATS && t0 >= tiles) return;          // (STATS: every wave reaches the barrier below; its loops run zero times)
   // The wave's work is one stream of (tile, 16-channel block) steps.  A load cursor runs CONV_AHEAD steps ahead of
   // the multiply cursor through a ring of register buffers, so a block has CONV_AHEAD multiply steps (of this wave
   // and of the waves sharing its SIMD) to arrive from HBM -- tile boundaries included.
@@ -129,7 +141,37 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
   cv_f32x4 acc[NBO][2];
 #pragma unroll
   for (int o = 0; o < NBO; ++o) acc[o][0] = acc[o][1] = cv_f32x4{0.f, 0.f, 0.f, 0.f};
-  while (mc.t < tiles) {
+  float st_s[STATS ? NBO : 1][4], st_q[STATS ? NBO : 1][4];
+  int st_tiles = 0;
+  if (STATS) {
+#pragma unroll
+    for (int o = 0; o < NBO; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st_s[o][r] = st_q[o][r] = 0.f;
+  }
+  double *st_slot = reinterpret_cast<double *>(const_cast<float4 *>(conv_in) + nbi * 16) + (size_t)wave * NBO * 16 * 2;
+  auto st_flush = [&]() {
+    struct AddF { __device__ __forceinline__ unsigned operator()(unsigned a, unsigned b) const {
+      return __float_as_uint(__uint_as_float(a) + __uint_as_float(b)); } };
+#pragma unroll
+    for (int o = 0; o < (STATS ? NBO : 0); ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ss = __uint_as_float(row16_allreduce_u32(__float_as_uint(st_s[o][r]), AddF()));
+        const float qq = __uint_as_float(row16_allreduce_u32(__float_as_uint(st_q[o][r]), AddF()));
+        if (j == 0) {                        // the row's channel 16 o + 4 g + r: this lane alone owns the slot
+          double *d = st_slot + (o * 16 + 4 * g + r) * 2;
+          d[0] += (double)ss;
+          d[1] += (double)qq;
+        }
+        st_s[o][r] = st_q[o][r] = 0.f;
+      }
+    st_tiles = 0;
+  };
+  // (STATS: one extra trip after the last tile, so that the flush below exists ONCE in the code -- five inlined copies of
+  // it pushed the ring buffer out of registers)
+  for (bool more = true; more;) {
+    more = mc.t < tiles;
 #pragma unroll
     for (int u = 0; u < CONV_AHEAD; ++u) {
       if (mc.t < tiles) {                    // wave-uniform
@@ -173,6 +215,10 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
                   v1 = v1 * sc + sh;
                   if (ep_relu) { v0 = relu_nan(v0); v1 = relu_nan(v1); }
                 }
+                if (STATS) {                  // padding channels hold exact zeros: they add nothing and are never read
+                  st_s[o][r] += v0 + v1;
+                  st_q[o][r] = fmaf(v1, v1, fmaf(v0, v0, st_q[o][r]));
+                }
                 if (ep_pool > 0) {
                   float mx = max_nan(v0, v1);
                   for (int off = 1; off < (ep_pool >> 1); off <<= 1) mx = max_nan(mx, __shfl_xor(mx, off, 64));
@@ -184,9 +230,23 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : 2)) void conv1x1_kern
           }
 #pragma unroll
           for (int o = 0; o < NBO; ++o) acc[o][0] = acc[o][1] = cv_f32x4{0.f, 0.f, 0.f, 0.f};
+          if (STATS) ++st_tiles;
         }
         advance(mc);
       }
+    }
+    if (STATS && (st_tiles >= CONV_STAT_TILES || !more)) st_flush();     // at most CONV_AHEAD - 1 tiles over the limit
+  }
+  if (STATS) {
+    __syncthreads();
+    const double *slots = reinterpret_cast<const double *>(conv_in + nbi * 16);
+    for (int e = threadIdx.x; e < NBO * 16 * 2; e += CONV_THREADS) {
+      const int co = 16 * ob0 + (e >> 1);
+      if (co >= Cout) continue;
+      double t = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < CONV_WAVES; ++wv) t += slots[(size_t)wv * NBO * 16 * 2 + e];
+      stats_partial[((size_t)co * gridDim.x + blockIdx.x) * 2 + (e & 1)] = t;
     }
   }
 }
@@ -444,10 +504,29 @@ static bool conv_args_ok(const char *what, int b, int cin, int cout, int p, cons
 
 using namespace pwclo;
 
+// Launch shape of the forward / input-gradient kernel: gy groups of nbo output blocks, gx persistent tile workers.
+struct ConvGrid { int nbi, nbo, gy; long long gx; size_t lds; };
+static ConvGrid conv_grid(int b, int cin, int cout, int p, bool stats) {
+  ConvGrid cg;
+  cg.nbi = ceil_div(cin, 16);
+  const int nbo_all = ceil_div(cout, 16);
+  cg.gy = ceil_div(nbo_all, CONV_MAX_NBO);                              // groups of output blocks (input re-read per group)
+  cg.nbo = ceil_div(nbo_all, cg.gy);
+  cg.lds = (size_t)cg.nbo * cg.nbi * WAVE * sizeof(float4) + (size_t)cg.nbi * 16 * sizeof(float4);   // weights + input transform
+  if (stats) cg.lds += (size_t)CONV_WAVES * cg.nbo * 16 * 2 * sizeof(double);                        // + the waves' fp64 slots
+  const long long tiles = (long long)b * ceil_div(p, 32);
+  const int per_cu = (cg.lds <= 72 * 1024 && cg.nbo <= 3) ? 2 : 1;      // workgroups a CU can hold (LDS, registers)
+  cg.gx = (long long)conv_grid_x() * per_cu / cg.gy;
+  const long long need = (tiles + CONV_WAVES - 1) / CONV_WAVES;
+  if (cg.gx > need) cg.gx = need;
+  if (cg.gx < 1) cg.gx = 1;
+  return cg;
+}
+
 static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, const float *w, int transposed, float *y,
                            const float *scale, const float *shift, int relu, int pool = 0,
                            const float *in_mean = nullptr, const float *in_invstd = nullptr,
-                           const float *in_gamma = nullptr, const float *in_beta = nullptr) {
+                           const float *in_gamma = nullptr, const float *in_beta = nullptr, double *stats = nullptr) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0) return;
   if (!conv_args_ok("conv1x1_forward", b, cin, cout, p, x, y, x)) return;
   PWCLO_REQUIRE((scale == nullptr) == (shift == nullptr), "conv1x1_forward: scale and shift must be given together%s", "");
@@ -455,25 +534,21 @@ static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, cons
                 "conv1x1_forward: pooled rows of k=%d pixels need k in {4,8,16,32} dividing p=%d", pool, p);
   // transposed = 1: w is stored (cin, cout) row-major -- the input-gradient pass of a layer whose weight it is.
   const long long ld_o = transposed ? 1 : cin, ld_i = transposed ? cout : 1;
-  const int nbi = ceil_div(cin, 16), nbo_all = ceil_div(cout, 16);
-  const int gy = ceil_div(nbo_all, CONV_MAX_NBO);                       // groups of output blocks (input re-read per group)
-  const int nbo = ceil_div(nbo_all, gy);
-  const size_t lds = (size_t)nbo * nbi * WAVE * sizeof(float4) + (size_t)nbi * 16 * sizeof(float4);   // weights + input transform
+  const ConvGrid cg = conv_grid(b, cin, cout, p, stats != nullptr);
+  const int nbi = cg.nbi, nbo = cg.nbo, gy = cg.gy;
+  const size_t lds = cg.lds;
+  const long long gx = cg.gx;
   PWCLO_REQUIRE((in_mean == nullptr) == (in_invstd == nullptr), "conv1x1_forward: in_mean and in_invstd must be given together%s", "");
   PWCLO_REQUIRE(lds <= 154 * 1024, "conv1x1_forward: cin=%d cout=%d need %zu bytes of LDS for the weights", cin, cout, lds);
-  const long long tiles = (long long)b * ceil_div(p, 32);
-  const int per_cu = (lds <= 72 * 1024 && nbo <= 3) ? 2 : 1;             // workgroups a CU can hold (LDS, registers)
-  long long gx = (long long)conv_grid_x() * per_cu / gy;
-  const long long need = (tiles + CONV_WAVES - 1) / CONV_WAVES;
-  if (gx > need) gx = need;
-  if (gx < 1) gx = 1;
   hipStream_t st = current_stream();
   dim3 grid((unsigned)gx, (unsigned)gy), block(CONV_THREADS);
+#define PWCLO_CONV_LAUNCH_S(N, S)                                                                                \
+    PWCLO_REQUIRE(allow_lds(conv1x1_kernel<N, S>, lds), "conv1x1_forward: cannot reserve %zu bytes of LDS", lds); \
+    hipLaunchKernelGGL((conv1x1_kernel<N, S>), grid, block, lds, st, b, cin, cout, p, nbi, ld_o, ld_i, x, w, y,   \
+                       scale, shift, relu, pool, in_mean, in_invstd, in_gamma, in_beta, stats);
 #define PWCLO_CONV_LAUNCH(N)                                                                                     \
   case N:                                                                                                        \
-    PWCLO_REQUIRE(allow_lds(conv1x1_kernel<N>, lds), "conv1x1_forward: cannot reserve %zu bytes of LDS", lds);    \
-    hipLaunchKernelGGL((conv1x1_kernel<N>), grid, block, lds, st, b, cin, cout, p, nbi, ld_o, ld_i, x, w, y,      \
-                       scale, shift, relu, pool, in_mean, in_invstd, in_gamma, in_beta);                         \
+    if (stats != nullptr) { PWCLO_CONV_LAUNCH_S(N, true) } else { PWCLO_CONV_LAUNCH_S(N, false) }                \
     break
   switch (nbo) {
     PWCLO_CONV_LAUNCH(1);
@@ -487,6 +562,7 @@ static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, cons
       PWCLO_CONV_LAUNCH(8);
   }
 #undef PWCLO_CONV_LAUNCH
+#undef PWCLO_CONV_LAUNCH_S
   check_launch("conv1x1_forward");
 }
 
@@ -504,6 +580,34 @@ extern "C" void conv1x1_bnrelu_forward_kernel_wrapper(int b, int cin, int cout, 
                                                       const float *in_mean, const float *in_invstd,
                                                       const float *in_gamma, const float *in_beta, float *y) {
   conv1x1_launch(b, cin, cout, p, x, w, 0, y, nullptr, nullptr, 0, 0, in_mean, in_invstd, in_gamma, in_beta);
+}
+
+// Training forward of conv -> BatchNorm: y = W x (x optionally max(bn_prev(x), 0) applied on load, as above), and the
+// batch statistics of y -- save_mean, save_invstd, the momentum update of running_mean / running_var (nullable) -- from
+// the convolution's own epilogue sums: what batchnorm_train_forward_kernel_wrapper(y = nullptr) computes with a pass over y.
+// workspace: conv1x1_stats_workspace_bytes(b, cin, cout, p) bytes.
+extern "C" long long conv1x1_stats_workspace_bytes(int b, int cin, int cout, int p) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0) return 0;
+  const ConvGrid cg = conv_grid(b, cin, cout, p, true);
+  return (long long)cout * cg.gx * 2 * (long long)sizeof(double);
+}
+
+extern "C" void conv1x1_forward_bnstats_kernel_wrapper(int b, int cin, int cout, int p, const float *x, const float *w,
+                                                       const float *in_mean, const float *in_invstd,
+                                                       const float *in_gamma, const float *in_beta, float *y, float eps,
+                                                       float momentum, float *running_mean, float *running_var,
+                                                       float *save_mean, float *save_invstd, void *workspace) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0) return;
+  PWCLO_REQUIRE(workspace != nullptr && save_mean != nullptr && save_invstd != nullptr,
+                "conv1x1_forward_bnstats: workspace, save_mean and save_invstd are required%s", "");
+  PWCLO_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+                "conv1x1_forward_bnstats: running_mean and running_var must be given together%s", "");
+  const ConvGrid cg = conv_grid(b, cin, cout, p, true);
+  PWCLO_REQUIRE(cg.lds <= 154 * 1024, "conv1x1_forward_bnstats: cin=%d cout=%d need %zu bytes of LDS", cin, cout, cg.lds);
+  double *partial = reinterpret_cast<double *>(workspace);
+  conv1x1_launch(b, cin, cout, p, x, w, 0, y, nullptr, nullptr, 0, 0, in_mean, in_invstd, in_gamma, in_beta, partial);
+  bn_forward_finish_launch(cout, (int)cg.gx, (long long)b * p, eps, momentum, partial, running_mean, running_var, save_mean,
+                           save_invstd);
 }
 
 extern "C" void conv1x1_affine_maxk_forward_kernel_wrapper(int b, int cin, int cout, int s, int k, const float *x,

@@ -145,6 +145,7 @@ class _ConvBlock(nn.Sequential):
 # training-mode stacks: interior BatchNorm + ReLU folded into the next layer's convolution (conv1x1._BNReluConv), the last
 # layer's into the stack tail; "0" keeps one BatchNorm pass per layer
 _USE_HIP_STACK = os.environ.get("PWCLO_HIP_STACK", "1") != "0"
+_USE_CONV_STATS = os.environ.get("PWCLO_CONV_STATS", "1") != "0"     # BatchNorm statistics from the convolution epilogues
 
 
 def _train_stack(mlp, x, pooled):
@@ -167,10 +168,18 @@ def _train_stack(mlp, x, pooled):
         blocks.append((mods[0], mods[1][0]))
     if blocks[0][0].in_channels != x.shape[1] or (pooled and x.shape[3] not in (4, 8, 16, 32)):
         return None
+    last_bn = blocks[-1][1]
+    if _USE_CONV_STATS:
+        # every convolution sums the batch statistics of its own output in its epilogue: no statistics pass over any
+        # activation of the stack
+        y, stats = _hip_conv.conv1x1_stats(x, blocks[0][0], blocks[0][1])
+        for (_, bn_prev), (conv, bn) in zip(blocks[:-1], blocks[1:]):
+            y, stats = _hip_conv.bn_relu_conv(y, bn_prev, conv, stats=stats, next_bn=bn)
+        return (_hip_bn.batch_norm_train_relu_max(y, last_bn, stats=stats) if pooled
+                else _hip_bn.batch_norm_train(y, last_bn, relu=True, stats=stats))
     y = _hip_conv.conv1x1(x, blocks[0][0].weight)
     for (_, bn_prev), (conv, _) in zip(blocks[:-1], blocks[1:]):
         y = _hip_conv.bn_relu_conv(y, bn_prev, conv)
-    last_bn = blocks[-1][1]
     return _hip_bn.batch_norm_train_relu_max(y, last_bn) if pooled else _hip_bn.batch_norm_train(y, last_bn, relu=True)
 
 

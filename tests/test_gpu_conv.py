@@ -402,6 +402,54 @@ def test_training_stack_without_normalised_activations_matches_torch(cuda, poole
             assert int(p) == 1, n                             # num_batches_tracked (the float64 copy was not advanced)
 
 
+@pytest.mark.parametrize("B,cin,cout,P,shift", [(2, 6, 8, 4096, 0.0), (3, 35, 48, 1028, 0.0), (1, 64, 128, 64, 0.0),
+                                                 (2, 138, 128, 512, 0.0), (2, 19, 200, 260, 0.0), (1, 3, 5, 4, 0.0),
+                                                 (64, 8, 16, 65536, 3.0), (4, 67, 64, 16384, 5.0)])
+@pytest.mark.parametrize("transform", [False, True])
+def test_conv_epilogue_batch_statistics(cuda, B, cin, cout, P, shift, transform):
+    """conv1x1_forward_bnstats: the convolution's output is bit-identical to the plain kernel's, and the batch statistics
+    summed in its epilogue (per-lane fp32 over <= 64 values, fp64 beyond) equal a float64 evaluation of
+    F.batch_norm(training=True)'s mean / biased variance / running update on that output: 2e-6 of |mean| + std, 5e-6
+    relative for 1/sqrt(var + eps) -- also where |mean| is several standard deviations (``shift``) and on the largest
+    activation of the training step (64 x 16 x 65536: 32 tiles per wave)."""
+    from pwclonet_pylidarslam_amd import _lib, conv1x1
+    if B * (cin + cout) * P * 4 > 2 ** 31:
+        pytest.skip("too large")
+    gen = torch.Generator().manual_seed(cin * 131 + cout)
+    x = (torch.randn(B, cin, P, generator=gen) + shift).to(cuda)
+    w = (torch.randn(cout, cin, generator=gen) / cin ** 0.5).to(cuda)
+    tf = None
+    if transform:
+        tf = tuple(t.to(cuda) for t in (torch.randn(cin, generator=gen), torch.rand(cin, generator=gen) + 0.5,
+                                        torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen) * 0.3))
+    rm = torch.randn(cout, generator=gen).to(cuda)
+    rv = (torch.rand(cout, generator=gen) + 0.5).to(cuda)
+    rm0, rv0 = rm.clone(), rv.clone()
+    eps, mom = 1e-5, 0.1
+    y, mean, invstd = conv1x1._forward_stats(x, w, cin, cout, tf, rm, rv, mom, eps)
+    if transform:
+        plain = torch.empty_like(y)
+        _lib.call("conv1x1_bnrelu_forward_kernel_wrapper", x.device, B, cin, cout, P, x.data_ptr(), w.data_ptr(),
+                  tf[0].data_ptr(), tf[1].data_ptr(), tf[2].data_ptr(), tf[3].data_ptr(), plain.data_ptr())
+    else:
+        plain = conv1x1._forward(x, w, False, cin, cout)
+    assert torch.equal(y, plain)
+    y64 = y.double()
+    m64 = y64.mean(dim=(0, 2))
+    v64 = y64.var(dim=(0, 2), unbiased=False)
+    sd = v64.sqrt()
+    assert ((mean.double() - m64).abs() <= 2e-6 * (m64.abs() + sd) + 1e-12).all(), ((mean.double() - m64).abs() / (m64.abs() + sd)).max()
+    is64 = 1.0 / torch.sqrt(v64 + eps)
+    rel = ((invstd.double() - is64).abs() / is64).max().item()
+    assert rel <= 5e-6, rel
+    n = B * P
+    unb = v64 * n / max(n - 1, 1)
+    torch.testing.assert_close(rm.double(), (1 - mom) * rm0.double() + mom * m64, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv.double(), (1 - mom) * rv0.double() + mom * unb, rtol=1e-5, atol=1e-6)
+    y2, mean2, invstd2 = conv1x1._forward_stats(x, w, cin, cout, tf, None, None, mom, eps)      # deterministic
+    assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2)
+
+
 @pytest.mark.parametrize("K", [4, 6, 32, 8])
 def test_softmax_weighted_sum_matches_torch(cuda, K):
     """csrc/softmax_wsum.hip behind pwclonet/costvolume.py: sum(softmax(x, dim=3) * v, dim=3), forward and both gradients,

@@ -202,15 +202,27 @@ def test_train_mode_hip_kernels_against_torch_ops(cuda, deterministic, monkeypat
     print("torch's GPU ops on the same network: worst gradient error vs float64 %.2e of max|g|" % worst_t)
 
 
-@pytest.mark.parametrize("stack", [True, False])
+@pytest.mark.parametrize("stack", ["default", "stack_stats_pass", "layerwise", "torch"])
 def test_train_step_at_config3_per_gpu_share(cuda, deterministic, monkeypatch, stack):
     """configs[3]'s per-GPU share -- B = 32 pairs of 2 x 8192 points, the shapes tools/train_step.py times: ONE
     optimizer step (slam/training/trainer.py:624-628).  Finite loss, every parameter receives a finite gradient,
-    eager step == graphed step (same kernels, deterministic scatter-adds: within 1e-6 of scale), and the stack fusion
-    (PWCLO_HIP_STACK=1) == layer-by-layer kernels (=0) within 1e-5 of each gradient's scale.  Guards the real-size
-    paths (wgrad split rule, LDS limits, 32-bit offsets on 268 MB tensors) that the small fixtures do not reach."""
+    eager step == graphed step (same kernels, deterministic scatter-adds: within 1e-6 of scale).  Across modes:
+      * the stack fusion with a statistics pass per BatchNorm (PWCLO_CONV_STATS=0) == layer-by-layer kernels
+        (PWCLO_HIP_STACK=0) within 1e-5 of each gradient's scale: same fp64 statistics, same sums;
+      * the default (statistics from the convolution epilogues: equal to the fp64 pass to ~1e-6, tests/test_gpu_conv.py)
+        against the statistics-pass stack: batch-statistic BatchNorm backward amplifies a 1e-6 change of the statistics
+        like any other fp32 rounding (the reference's own fp32 gradients are 3e-4 ... 1.4e-2 of
+        max|g| from its float64 evaluation), so the yardstick is measured here: torch's own convolution / batch_norm
+        ops on the same network against the layer-by-layer kernels; bounds on the distribution over the parameter
+        tensors: worst <= 4 x, rms and median <= 2 x the yardstick's.
+    Guards the real-size paths (wgrad split rule, LDS limits, 32-bit offsets on 268 MB tensors) that the small fixtures
+    do not reach."""
     import bench
-    monkeypatch.setattr(pt, "_USE_HIP_STACK", stack)
+    monkeypatch.setattr(pt, "_USE_HIP_STACK", stack in ("default", "stack_stats_pass"))
+    monkeypatch.setattr(pt, "_USE_CONV_STATS", stack == "default")
+    if stack == "torch":
+        monkeypatch.setattr(pt, "_USE_HIP_CONV", "0")
+        monkeypatch.setattr(pt, "_USE_HIP_BN", False)
     torch.manual_seed(7)
     net = PWCLONet(dict(num_input_channels=3, sequence_len=2, device=str(cuda), scalar_last=False, log_mode="none",
                         fused="off")).to(cuda)
@@ -237,28 +249,49 @@ def test_train_step_at_config3_per_gpu_share(cuda, deterministic, monkeypatch, s
     for k, gk in grads_e.items():
         assert gk is not None and torch.isfinite(gk).all(), k
     assert any((state_e[k] != init[k]).any() for k in init if k.endswith("conv.weight"))     # the optimizer stepped
-    loss_e2, grads_e2, _ = one_step(False)                  # the eager step's own run-to-run difference
-    noise = max((grads_e2[k] - ge).abs().max().item() / max(ge.abs().max().item(), 1e-30) for k, ge in grads_e.items())
-    loss_g, grads_g, _ = one_step(True)
-    assert abs(loss_g.item() - loss_e.item()) <= 1e-6 * abs(loss_e.item()), (loss_g.item(), loss_e.item())
-    worst = 0.0
-    for k, ge in grads_e.items():
-        err, scale = (grads_g[k] - ge).abs().max().item(), ge.abs().max().item()
-        worst = max(worst, err / max(scale, 1e-30))
-        assert err <= (4.0 * noise + 1e-6) * scale + 1e-12, (k, err, scale, noise)
-    print("\nB=32 2x8192 train step (stack fusion %s): loss %.4f, eager vs graphed worst gradient difference %.1e of scale "
-          "(eager run-to-run: %.1e)" % (stack, loss_e.item(), worst, noise))
-    _NOISE[stack] = noise
     _STEP_RESULTS[stack] = (loss_e, grads_e)
-    if len(_STEP_RESULTS) == 2:
-        (la, ga), (lb, gb) = _STEP_RESULTS[True], _STEP_RESULTS[False]
-        assert abs(la.item() - lb.item()) <= 1e-5 * abs(lb.item())
-        w = 0.0
-        for k in ga:
-            err, scale = (ga[k] - gb[k]).abs().max().item(), gb[k].abs().max().item()
-            w = max(w, err / max(scale, 1e-30))
-            assert err <= max(1e-5, 4.0 * max(_NOISE.values())) * scale + 1e-10, (k, err, scale)
-        print("stack fusion on vs off at B=32: worst gradient difference %.1e of scale (bound max(1e-5, 4 x run-to-run))" % w)
+    if stack == "torch":                                    # the yardstick only: torch's ops are not what is under test
+        _NOISE[stack] = 0.0
+    else:
+        loss_e2, grads_e2, _ = one_step(False)              # the eager step's own run-to-run difference
+        noise = max((grads_e2[k] - ge).abs().max().item() / max(ge.abs().max().item(), 1e-30) for k, ge in grads_e.items())
+        loss_g, grads_g, _ = one_step(True)
+        assert abs(loss_g.item() - loss_e.item()) <= 1e-6 * abs(loss_e.item()), (loss_g.item(), loss_e.item())
+        worst = 0.0
+        for k, ge in grads_e.items():
+            err, scale = (grads_g[k] - ge).abs().max().item(), ge.abs().max().item()
+            worst = max(worst, err / max(scale, 1e-30))
+            assert err <= (4.0 * noise + 1e-6) * scale + 1e-12, (k, err, scale, noise)
+        print("\nB=32 2x8192 train step (%s): loss %.4f, eager vs graphed worst gradient difference %.1e of scale "
+              "(eager run-to-run: %.1e)" % (stack, loss_e.item(), worst, noise))
+        _NOISE[stack] = noise
+    if len(_STEP_RESULTS) == 4:
+        def diff(a, b):
+            (la, ga), (lb, gb) = _STEP_RESULTS[a], _STEP_RESULTS[b]
+            return abs(la.item() - lb.item()) / abs(lb.item()), \
+                {k: (ga[k] - gb[k]).abs().max().item() / max(gb[k].abs().max().item(), 1e-30) for k in ga}
+        floor = max(1e-5, 4.0 * max(_NOISE.values()))
+        dl, d = diff("stack_stats_pass", "layerwise")
+        assert dl <= 1e-5, dl
+        for k, e in d.items():
+            assert e <= floor + 1e-10, (k, e)
+        print("stack fusion (statistics pass) vs layer-by-layer at B=32: worst gradient difference %.1e of scale "
+              "(bound max(1e-5, 4 x run-to-run))" % max(d.values()))
+        _, yard = diff("torch", "layerwise")
+        dl, d = diff("default", "stack_stats_pass")
+        assert dl <= 1e-5, dl
+        # both differences are dominated by a few tensors behind a flipped near-tie (a neighbour list / arg-max that changes
+        # with the last bit of a pose estimate), which tensors those are differs between any two fp32 evaluations: compare
+        # the distributions over the parameter tensors, not tensor by tensor
+        rms = lambda v: float(np.sqrt(np.mean(np.square(list(v)))))
+        med = lambda v: float(np.median(list(v)))
+        print("statistics from the convolution epilogues vs the statistics pass at B=32, gradient difference per tensor in "
+              "units of max|g|: worst %.1e, rms %.1e, median %.1e; yardstick (torch's GPU ops vs the layer-by-layer kernels): "
+              "worst %.1e, rms %.1e, median %.1e" % (max(d.values()), rms(d.values()), med(d.values()), max(yard.values()),
+                                                     rms(yard.values()), med(yard.values())))
+        assert max(d.values()) <= 4.0 * max(yard.values()) + floor
+        assert rms(d.values()) <= 2.0 * rms(yard.values()) + floor
+        assert med(d.values()) <= 2.0 * med(yard.values()) + floor
 
 
 _STEP_RESULTS = {}
