@@ -169,15 +169,37 @@ class PWCLONet(nn.Module):
         self._fused = None
         return super().load_state_dict(*args, **kwargs)
 
-    def _pyramid(self, xyz_t, points, first_samples=None):
+    def _pyramid(self, xyz_t, points, samples=None):
+        """``samples``: the levels' sample coordinates where the caller has already drawn them (a list, possibly shorter
+        than the pyramid: the remaining levels sample for themselves)."""
         levels = []
         x, f = xyz_t, points
         for k, sa in enumerate((self.psa_1, self.psa_2, self.psa_3, self.psa_4)):
-            x, f = sa(x, f, new_xyz=first_samples) if (k == 0 and first_samples is not None) else sa(x, f)
+            given = samples[k] if samples is not None and k < len(samples) else None
+            x, f = sa(x, f, new_xyz=given) if given is not None else sa(x, f)
             levels.append((x, f))
         return levels
 
-    def forward(self, xyz_f1, points_f1, xyz_f2, points_f2, bn_decay=None):
+    def sample_pyramid(self, xyz_f1, xyz_f2):
+        """The sample coordinates the four set-abstraction levels draw for both frames, xyz (B,3,N) -> two lists of
+        (B, npoint_l, 3) tensors.  They depend on the input coordinates only (no weights, no gradient), so a training
+        loop can draw them for the NEXT batch while the current step runs and hand them to ``forward(...,
+        samples=)`` (training.TrainStep(sample_ahead=True)): the level-1 sampler is the longest serial kernel of the
+        step -- one workgroup per cloud, 1.9 ms on a quarter of the compute units."""
+        cf = lambda z: z.permute(0, 2, 1).contiguous()
+        with torch.no_grad():
+            s1, s2 = pointnet2_utils.sample_and_gather_pair(cf(xyz_f1), cf(xyz_f2), self.psa_1.npoint)
+            a, b = [s1], [s2]
+            for sa in (self.psa_2, self.psa_3, self.psa_4):
+                a.append(pointnet2_utils.sample_and_gather(a[-1], sa.npoint))
+                b.append(pointnet2_utils.sample_and_gather(b[-1], sa.npoint))
+        return a, b
+
+    def forward(self, xyz_f1, points_f1, xyz_f2, points_f2, bn_decay=None, samples=None):
+        """``samples`` (not in the reference's signature): ``sample_pyramid(xyz_f1, xyz_f2)`` when the caller has
+        already drawn it -- module path only."""
+        if samples is not None and not (self.training and xyz_f1.is_cuda):
+            return self._forward_modules(xyz_f1, points_f1, xyz_f2, points_f2, samples)
         if self._fused is None and self.fuse_mode == "auto" and not self.training and not torch.is_grad_enabled() \
                 and points_f1 is None and points_f2 is None and xyz_f1.is_cuda \
                 and not torch.cuda.is_current_stream_capturing():
@@ -191,14 +213,17 @@ class PWCLONet(nn.Module):
         if self.training and xyz_f1.is_cuda:
             from .. import batchnorm as _hip_bn
             with _hip_bn.deferred_counters():       # the 93 `num_batches_tracked += 1` of a forward as one multi-tensor add
-                return self._forward_modules(xyz_f1, points_f1, xyz_f2, points_f2)
+                return self._forward_modules(xyz_f1, points_f1, xyz_f2, points_f2, samples)
         return self._forward_modules(xyz_f1, points_f1, xyz_f2, points_f2)
 
-    def _forward_modules(self, xyz_f1, points_f1, xyz_f2, points_f2):
+    def _forward_modules(self, xyz_f1, points_f1, xyz_f2, points_f2, samples=None):
         """The reference-shaped forward (PW/pwclo_net.py:109-207) on the HIP ops."""
         cf = lambda z: z.permute(0, 2, 1).contiguous()
         B = xyz_f1.size(0)
-        if (not self.training) and points_f1 is None and points_f2 is None \
+        if samples is not None:                  # every level's samples drawn by the caller (sample_pyramid)
+            l1 = self._pyramid(cf(xyz_f1), points_f1, samples[0])
+            l2 = self._pyramid(cf(xyz_f2), points_f2, samples[1])
+        elif (not self.training) and points_f1 is None and points_f2 is None \
                 and xyz_f1.shape == xyz_f2.shape:
             # Eval mode: the pyramid is siamese (shared weights) and every op is per-cloud with
             # BatchNorm running statistics, so both frames go through it as one batch of 2B clouds
@@ -211,11 +236,12 @@ class PWCLONet(nn.Module):
             # level's sampling (the longest serial kernel of the step, one workgroup per cloud) is drawn for both
             # frames in one launch
             c1, c2 = cf(xyz_f1), cf(xyz_f2)
-            s1 = s2 = None
+            sam1 = sam2 = None
             if xyz_f1.is_cuda and xyz_f1.shape == xyz_f2.shape and not (xyz_f1.requires_grad or xyz_f2.requires_grad):
                 s1, s2 = pointnet2_utils.sample_and_gather_pair(c1, c2, self.psa_1.npoint)
-            l1 = self._pyramid(c1, points_f1, s1)
-            l2 = self._pyramid(c2, points_f2, s2)
+                sam1, sam2 = [s1], [s2]
+            l1 = self._pyramid(c1, points_f1, sam1)
+            l2 = self._pyramid(c2, points_f2, sam2)
         (x11t, p11), (x12t, p12), (x13t, p13), (_x14t, p14) = l1
         (x21t, p21), (x22t, p22), (x23t, p23), _ = l2
         x11, x12, x13 = cf(x11t), cf(x12t), cf(x13t)

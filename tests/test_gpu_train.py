@@ -298,6 +298,52 @@ _STEP_RESULTS = {}
 _NOISE = {}
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_train_step_sampling_ahead_is_the_plain_step(cuda, deterministic, graph):
+    """TrainStep(sample_ahead=True): the next batch's furthest-point samples are drawn on a second stream while the
+    current batch's step runs and handed to forward(samples=).  Two steps on two different batches: losses and the
+    parameters after both optimizer steps equal the plain TrainStep's bit for bit (same samples, same kernels), eager
+    and as two hipGraphs."""
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        x1 = (torch.rand(2, 3, 2048, generator=g) * 40 - 20)
+        x2 = x1 + torch.randn(2, 3, 2048, generator=g) * 0.05
+        gt = torch.randn(2, 7, generator=g) * 0.1
+        gt[:, 3:] = torch.nn.functional.normalize(gt[:, 3:] + torch.tensor([1.0, 0, 0, 0]), dim=1)
+        return x1.to(cuda), x2.to(cuda), gt.to(cuda)
+
+    A, Bt = batch(11), batch(12)
+    unit = _unit(cuda)
+    init = {k: v.detach().clone() for k, v in unit.state_dict().items()}
+
+    def run(ahead):
+        unit.load_state_dict(init)
+        opt = torch.optim.Adam(unit.parameters(), lr=1e-3, capturable=graph, fused=True)
+        args = tuple(t.clone() for t in A)
+        ts = TrainStep(unit, opt, *args, graph=graph, warmup=1, sample_ahead=ahead)
+        unit.load_state_dict(init)                        # the graph's warm-up steps moved the weights
+        if ahead:
+            l1 = ts.step(next_batch=Bt).detach().clone()
+            l2 = ts.step().detach().clone()
+        else:
+            l1 = ts.step().detach().clone()
+            for dst, src in zip(args, Bt):
+                dst.copy_(src)
+            l2 = ts.step().detach().clone()
+        torch.cuda.synchronize()
+        return l1, l2, {k: v.detach().clone() for k, v in unit.state_dict().items()}
+
+    p1, p2, ps = run(False)
+    a1, a2, as_ = run(True)
+    assert torch.isfinite(p1) and torch.isfinite(p2) and p1.item() != p2.item()
+    assert torch.equal(p1, a1), (p1.item(), a1.item())
+    assert torch.equal(p2, a2), (p2.item(), a2.item())
+    for k in ps:                                          # (graphed: Adam's state carries the one warm-up step in both runs)
+        assert torch.equal(ps[k], as_[k]), k
+    with pytest.raises(ValueError):
+        TrainStep(unit, torch.optim.Adam(unit.parameters(), lr=1e-3), *A).step(next_batch=Bt)
+
+
 def test_eval_after_train_forward_uses_fresh_statistics(cuda):
     """the eval path's folded BatchNorm cache must not survive a training-mode forward that
     rewrote the running statistics through the kernels' raw pointers (no optimizer step in between)."""

@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one multi-tensor kernel")
     ap.add_argument("--graph", action="store_true",
                     help="capture forward + loss + backward + Adam into one hipGraph (single GPU only)")
+    ap.add_argument("--sample-ahead", action="store_true",
+                    help="draw the next batch's furthest-point samples on a second stream while this batch's step runs "
+                         "(training.TrainStep(sample_ahead=True); the synthetic batch is the same every step)")
     a = ap.parse_args()
     if a.gpus > 1 and not dist_util.launched_by_torchrun():      # supervise N fresh ranks; no GPU call made here
         sys.exit(dist_util.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
@@ -61,7 +64,7 @@ def main():
 
     if a.graph:
         assert world == 1, "--graph is the single-GPU variant (DDP's bucketed all-reduce is not captured here)"
-    step = TrainStep(model, opt, x1, x2, gt, graph=a.graph).step
+    step = TrainStep(model, opt, x1, x2, gt, graph=a.graph, sample_ahead=a.sample_ahead).step
 
     losses = [step().item() for _ in range(a.warmup)]
     dist_util.fence(dev)
@@ -75,7 +78,8 @@ def main():
         print(json.dumps({"metric": "PWCLO-Net training frame-pairs/sec (fwd+bwd+Adam), 2x%d-pt pairs" % a.npoints,
                           "value": world * a.batch * a.steps / dt, "unit": "frame-pairs/s", "n_gpus": world,
                           "ms_per_step": 1e3 * dt / a.steps, "batch_per_gpu": a.batch, "dtype": "f32",
-                          "launch": "one hipGraph per step" if a.graph else "eager (module graph, torch autograd)", "loss_first_last": [losses[0], losses[-1]],
+                          "launch": ("one hipGraph per step" if a.graph else "eager (module graph, torch autograd)")
+                          + (", next batch's sampling chain on a second stream" if a.sample_ahead else ""), "loss_first_last": [losses[0], losses[-1]],
                           "collective": ("DDP all-reduce of %d fp32 gradient values (network + loss weights), one bucket"
                                          % gradient_bucket_values(unit)) if world > 1 else "none"}), flush=True)
     dist_util.finish()
