@@ -21,7 +21,10 @@ class PWCLONetWithLoss(nn.Module):
         self.loss_module = loss_module
 
     def forward(self, xyz_f1, xyz_f2, gt_params, samples=None):
-        pose, _ = self.pwclonet(xyz_f1, None, xyz_f2, None, samples=samples)
+        if samples is None:
+            pose, _ = self.pwclonet(xyz_f1, None, xyz_f2, None)
+        else:
+            pose, _ = self.pwclonet(xyz_f1, None, xyz_f2, None, samples=samples)
         loss, log = self.loss_module(pose, gt_params)
         return loss, pose, log
 
