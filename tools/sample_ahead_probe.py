@@ -68,3 +68,24 @@ def mm_and_side_graph():
     for _ in range(20): torch.mm(a, b)
     torch.cuda.current_stream().wait_stream(ts.side)
 print("20 matmuls + side sampling graph %.2f ms" % timeit(mm_and_side_graph))
+# the step graph captured ON the non-default stream it is replayed on
+s3 = torch.cuda.Stream()
+g3 = torch.cuda.CUDAGraph()
+opt.zero_grad(set_to_none=True)
+torch.cuda.synchronize()
+with torch.cuda.graph(g3, stream=s3):
+    loss3, _, _ = ts._forward()
+    loss3.backward()
+    opt.step()
+torch.cuda.synchronize()
+def g3_alone():
+    s3.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s3): g3.replay()
+    torch.cuda.current_stream().wait_stream(s3)
+print("step graph captured and replayed on the same non-default stream, alone %.2f ms" % timeit(g3_alone))
+def g3_and_side():
+    s3.wait_stream(torch.cuda.current_stream()); ts.side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(ts.side): ts.sample_graph.replay()
+    with torch.cuda.stream(s3): g3.replay()
+    torch.cuda.current_stream().wait_stream(s3); torch.cuda.current_stream().wait_stream(ts.side)
+print("... beside the sampling graph on another stream %.2f ms" % timeit(g3_and_side))
