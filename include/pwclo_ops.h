@@ -330,6 +330,24 @@ void group_points_grad_sorted_strided_kernel_wrapper(int b, int c, int n, int np
                                                      const float *grad_out, long long batch_stride, const int *perm,
                                                      const int *seg, float *grad_points);
 
+/* Inputs of the cost volume's shared MLPs (PW/costvolume.py:92-107 first aggregate, :155-172 second): the 10-channel
+ * geometry encoding of every (centre p, neighbour q = src[idx]) pair, out[b, 0:10, j, t] = [p (3), q (3), q - p (3),
+ * sqrt(sum (q - p)^2 + 1e-20)], and the centre's features tiled over the k neighbours (torch.tile in the reference),
+ * written straight into their channel slice of the concatenated tensor (`out` = first channel of the slice in cloud 0,
+ * batch_stride floats between clouds, as the *_strided grouping entry points).  centre_xyz (b,3,s), src_xyz (b,3,n),
+ * idx (b,s,k) i32, feats (b,c,s).  Forward values are the reference's bit for bit.  Gradients: d_centre_xyz (b,3,s) is
+ * written; d_src_xyz (b,3,n) must be zero-filled and receives atomic adds; either may be NULL (not wanted); d_pair
+ * (b,3,s,k), instead of d_src_xyz, receives the neighbours' gradients pair by pair (for group_points_grad_sorted).
+ * broadcast_centre_grad: d_feats (b,c,s) = sum over the k neighbours of the slice's gradient. */
+void geometry_encode_kernel_wrapper(int b, int n, int s, int k, const float *centre_xyz, const float *src_xyz,
+                                    const int *idx, float *out, long long batch_stride);
+void geometry_encode_grad_kernel_wrapper(int b, int n, int s, int k, const float *centre_xyz, const float *src_xyz,
+                                         const int *idx, const float *grad_out, long long batch_stride,
+                                         float *d_centre_xyz, float *d_src_xyz, float *d_pair);
+void broadcast_centre_kernel_wrapper(int b, int c, int s, int k, const float *feats, float *out, long long batch_stride);
+void broadcast_centre_grad_kernel_wrapper(int b, int c, int s, int k, const float *grad_out, long long batch_stride,
+                                          float *d_feats);
+
 /* On-device front end of the dataset (slam/dataset/kitti_odometry_dataset.py:375-397, filter_pcd
  * :149-160): points (n,4) f32 raw velodyne rows (x,y,z,intensity), tr (12) f64 DEVICE array = rows of the
  * 3x4 calibration matrix Tr; xyz (n,3) f32 = Tr . (x,y,z,1) evaluated in fp64, keep (n) i32 = 1 where the

@@ -231,6 +231,123 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_sorted_kernel(
     if (l < nch) grad_points[((size_t)b * c + c0 + l) * n + i] = acc[l];
 }
 
+
+// ---- cost-volume inputs (PW/costvolume.py:92-107, 155-166) -----------------------------------------------------------
+// The reference builds the 10-channel geometry encoding [p, q, q - p, |q - p|] of every (centre p, neighbour q) pair with
+// tile / grouping_operation / sub / square / sum / sqrt / cat, and tiles the centre's features over the K neighbours before a
+// second cat: a dozen element-wise launches forward, two dozen backward, each a full pass over a (B, C, S, K) tensor.  These
+// four kernels write / differentiate those channels directly in their slice of the concatenated MLP input (`out` points
+// at the slice's first channel of cloud 0, rows of consecutive clouds `bstride` floats apart).  Forward values are the
+// reference's bit for bit: the same fp32 subtraction, products and left-to-right sum, no fused multiply-add.
+constexpr int GEO_THREADS = 256;
+
+__global__ __launch_bounds__(GEO_THREADS) void geometry_encode_kernel(int n, int s, int k, const float *__restrict__ centre,
+                                                                      const float *__restrict__ src,
+                                                                      const int *__restrict__ idx, float *__restrict__ out,
+                                                                      long long bstride) {
+  const int b = blockIdx.y;
+  const int P = s * k;
+  const int p = blockIdx.x * GEO_THREADS + threadIdx.x;
+  if (p >= P) return;
+  const int j = p / k;
+  const int i = idx[(size_t)b * P + p];
+  const float *c = centre + (size_t)b * 3 * s, *q = src + (size_t)b * 3 * n;
+  const float px = c[j], py = c[s + j], pz = c[2 * s + j];
+  const float qx = q[i], qy = q[n + i], qz = q[2 * n + i];
+  const float dx = qx - px, dy = qy - py, dz = qz - pz;
+  const float e = sqrtf(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)), 1e-20f));
+  float *o = out + (size_t)b * bstride + p;
+  o[0] = px; o[(size_t)P] = py; o[(size_t)2 * P] = pz;
+  o[(size_t)3 * P] = qx; o[(size_t)4 * P] = qy; o[(size_t)5 * P] = qz;
+  o[(size_t)6 * P] = dx; o[(size_t)7 * P] = dy; o[(size_t)8 * P] = dz;
+  o[(size_t)9 * P] = e;
+}
+
+// One thread per centre: the K neighbour gradients of a centre are consecutive.  d_centre (B, 3, S) is written (the sum over
+// the centre's K pairs, in neighbour order: deterministic); d_src (B, 3, N), when wanted, is zero-filled by the caller and
+// receives atomic adds (or none at all: the pyramid's coordinates need no gradient); d_pair (B, 3, S, K) instead takes the
+// neighbours' gradients pair by pair, for the caller's atomics-free sorted scatter (group_points_grad_sorted).
+__global__ __launch_bounds__(GEO_THREADS) void geometry_encode_grad_kernel(int n, int s, int k, const float *__restrict__ centre,
+                                                                           const float *__restrict__ src,
+                                                                           const int *__restrict__ idx,
+                                                                           const float *__restrict__ g, long long bstride,
+                                                                           float *__restrict__ d_centre,
+                                                                           float *__restrict__ d_src,
+                                                                           float *__restrict__ d_pair) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * GEO_THREADS + threadIdx.x;
+  if (j >= s) return;
+  const int P = s * k;
+  const float *c = centre + (size_t)b * 3 * s, *q = src + (size_t)b * 3 * n;
+  const float px = c[j], py = c[s + j], pz = c[2 * s + j];
+  const float *gb = g + (size_t)b * bstride + (size_t)j * k;
+  const int *ib = idx + (size_t)b * P + (size_t)j * k;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int t = 0; t < k; ++t) {
+    const int i = ib[t];
+    const float dx = q[i] - px, dy = q[n + i] - py, dz = q[2 * n + i] - pz;
+    const float e = sqrtf(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)), 1e-20f));
+    const float ge = gb[(size_t)9 * P + t] / e;                      // d|q - p| / d(q - p) = (q - p) / |q - p|
+    const float ddx = gb[(size_t)6 * P + t] + ge * dx, ddy = gb[(size_t)7 * P + t] + ge * dy,
+                ddz = gb[(size_t)8 * P + t] + ge * dz;              // gradient w.r.t. the difference q - p
+    ax += gb[t] - ddx;
+    ay += gb[(size_t)P + t] - ddy;
+    az += gb[(size_t)2 * P + t] - ddz;
+    if (d_src != nullptr) {
+      float *ds = d_src + (size_t)b * 3 * n;
+      atomicAdd(ds + i, gb[(size_t)3 * P + t] + ddx);
+      atomicAdd(ds + n + i, gb[(size_t)4 * P + t] + ddy);
+      atomicAdd(ds + 2 * n + i, gb[(size_t)5 * P + t] + ddz);
+    } else if (d_pair != nullptr) {          // per-pair neighbour gradients (b, 3, s, k) for the atomics-free scatter
+      float *dp = d_pair + (size_t)b * 3 * P + (size_t)j * k + t;
+      dp[0] = gb[(size_t)3 * P + t] + ddx;
+      dp[(size_t)P] = gb[(size_t)4 * P + t] + ddy;
+      dp[(size_t)2 * P] = gb[(size_t)5 * P + t] + ddz;
+    }
+  }
+  if (d_centre != nullptr) {
+    float *dc = d_centre + (size_t)b * 3 * s;
+    dc[j] = ax; dc[s + j] = ay; dc[2 * s + j] = az;
+  }
+}
+
+// out[b, c, j, t] = feats[b, c, j] for t < k (the reference's torch.tile of the centre features); grid (P / 4 / T, c, b).
+__global__ __launch_bounds__(GEO_THREADS) void broadcast_centre_kernel(int c, int s, int k, const float *__restrict__ feats,
+                                                                       float *__restrict__ out, long long bstride) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const int P = s * k;
+  const int p = (blockIdx.x * GEO_THREADS + threadIdx.x) * 4;
+  if (p >= P) return;
+  const float *f = feats + ((size_t)b * c + ch) * s;
+  float *o = out + (size_t)b * bstride + (size_t)ch * P + p;
+  if (p + 3 < P && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v = {f[p / k], f[(p + 1) / k], f[(p + 2) / k], f[(p + 3) / k]};
+    *reinterpret_cast<f4 *>(o) = v;
+  } else {
+    for (int u = 0; u < 4 && p + u < P; ++u) o[u] = f[(p + u) / k];
+  }
+}
+
+// d_feats[b, c, j] = sum_t grad[b, c, j, t] in neighbour order; one thread per (c, j).
+__global__ __launch_bounds__(GEO_THREADS) void broadcast_centre_grad_kernel(int c, int s, int k, const float *__restrict__ g,
+                                                                            long long bstride, float *__restrict__ d_feats) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const int j = blockIdx.x * GEO_THREADS + threadIdx.x;
+  if (j >= s) return;
+  const float *gb = g + (size_t)b * bstride + ((size_t)ch * s + j) * k;
+  float a = 0.f;
+  if ((k & 3) == 0 && ((reinterpret_cast<uintptr_t>(gb) & 15) == 0)) {
+    for (int t = 0; t < k; t += 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(gb + t);
+      a += v.x; a += v.y; a += v.z; a += v.w;
+    }
+  } else {
+    for (int t = 0; t < k; ++t) a += gb[t];
+  }
+  d_feats[((size_t)b * c + ch) * s + j] = a;
+}
+
 }  // namespace pwclo
 
 using namespace pwclo;
@@ -387,4 +504,45 @@ static void gp_grad(int b, int c, int n, int npoints, int nsample, const float *
   hipLaunchKernelGGL(group_points_grad_kernel, dim3(ceil_div(P, GP_THREADS), ceil_div(c, GP_CH_PER_BLOCK), b),
                      dim3(GP_THREADS), 0, current_stream(), c, n, P, grad_out, idx, grad_points, go_bstride);
   check_launch("group_points_grad");
+}
+
+extern "C" void geometry_encode_kernel_wrapper(int b, int n, int s, int k, const float *centre_xyz, const float *src_xyz,
+                                               const int *idx, float *out, long long batch_stride) {
+  if (b <= 0 || s <= 0 || k <= 0) return;
+  PWCLO_REQUIRE(n > 0 && b <= 65535 && (long long)s * k < (1ll << 31), "geometry_encode: b=%d n=%d s*k=%lld out of range", b, n,
+                (long long)s * k);
+  hipLaunchKernelGGL(geometry_encode_kernel, dim3(ceil_div(s * k, GEO_THREADS), b), dim3(GEO_THREADS), 0, current_stream(), n, s,
+                     k, centre_xyz, src_xyz, idx, out, batch_stride);
+  check_launch("geometry_encode");
+}
+
+extern "C" void geometry_encode_grad_kernel_wrapper(int b, int n, int s, int k, const float *centre_xyz, const float *src_xyz,
+                                                    const int *idx, const float *grad_out, long long batch_stride,
+                                                    float *d_centre_xyz, float *d_src_xyz, float *d_pair) {
+  if (b <= 0 || s <= 0 || k <= 0 || (d_centre_xyz == nullptr && d_src_xyz == nullptr && d_pair == nullptr)) return;
+  PWCLO_REQUIRE(d_src_xyz == nullptr || d_pair == nullptr, "geometry_encode_grad: d_src_xyz and d_pair are alternatives%s", "");
+  PWCLO_REQUIRE(n > 0 && b <= 65535 && (long long)s * k < (1ll << 31), "geometry_encode_grad: b=%d n=%d s*k=%lld out of range", b,
+                n, (long long)s * k);
+  hipLaunchKernelGGL(geometry_encode_grad_kernel, dim3(ceil_div(s, GEO_THREADS), b), dim3(GEO_THREADS), 0, current_stream(), n, s,
+                     k, centre_xyz, src_xyz, idx, grad_out, batch_stride, d_centre_xyz, d_src_xyz, d_pair);
+  check_launch("geometry_encode_grad");
+}
+
+extern "C" void broadcast_centre_kernel_wrapper(int b, int c, int s, int k, const float *feats, float *out,
+                                                long long batch_stride) {
+  if (b <= 0 || c <= 0 || s <= 0 || k <= 0) return;
+  PWCLO_REQUIRE(b <= 65535 && c <= 65535 && (long long)s * k < (1ll << 31), "broadcast_centre: b=%d c=%d s*k=%lld out of range", b,
+                c, (long long)s * k);
+  hipLaunchKernelGGL(broadcast_centre_kernel, dim3(ceil_div(ceil_div(s * k, 4), GEO_THREADS), c, b), dim3(GEO_THREADS), 0,
+                     current_stream(), c, s, k, feats, out, batch_stride);
+  check_launch("broadcast_centre");
+}
+
+extern "C" void broadcast_centre_grad_kernel_wrapper(int b, int c, int s, int k, const float *grad_out, long long batch_stride,
+                                                     float *d_feats) {
+  if (b <= 0 || c <= 0 || s <= 0 || k <= 0) return;
+  PWCLO_REQUIRE(b <= 65535 && c <= 65535, "broadcast_centre_grad: b=%d c=%d exceed the grid limits", b, c);
+  hipLaunchKernelGGL(broadcast_centre_grad_kernel, dim3(ceil_div(s, GEO_THREADS), c, b), dim3(GEO_THREADS), 0, current_stream(), c,
+                     s, k, grad_out, batch_stride, d_feats);
+  check_launch("broadcast_centre_grad");
 }

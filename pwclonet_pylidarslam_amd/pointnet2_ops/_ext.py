@@ -283,6 +283,60 @@ def group_points_grad_from(grad_stack, c_off, c, idx, n, deterministic=False, in
     return out
 
 
+def geometry_encode_into(centre_xyz, src_xyz, idx, stack, c_off):
+    """``stack[:, c_off:c_off+10]`` = [p, q, q - p, |q - p|] of PW/costvolume.py:92-105 (centre_xyz (B,3,S), src_xyz (B,3,N),
+    idx (B,S,K))."""
+    _float(centre_xyz, "centre_xyz"); _float(src_xyz, "src_xyz"); _int(idx, "idx"); _gpu(centre_xyz, src_xyz, idx, stack)
+    B, S, K = idx.shape
+    if centre_xyz.shape != (B, 3, S) or src_xyz.shape[:2] != (B, 3) or tuple(stack.shape[0:1] + stack.shape[2:]) != (B, S, K):
+        raise ValueError("geometry_encode: centre %s src %s idx %s stack %s" % (tuple(centre_xyz.shape), tuple(src_xyz.shape),
+                                                                                 tuple(idx.shape), tuple(stack.shape)))
+    ptr, stride = _slice_ptr(stack, c_off, 10)
+    _lib.call("geometry_encode_kernel_wrapper", idx.device, B, src_xyz.shape[2], S, K, _p(centre_xyz), _p(src_xyz), _p(idx), ptr,
+              stride)
+
+
+def geometry_encode_grad_from(grad_stack, c_off, centre_xyz, src_xyz, idx, want_centre=True, want_src=True,
+                              deterministic=False, inverse=None):
+    """-> (d_centre_xyz (B,3,S) or None, d_src_xyz (B,3,N) or None) from ``grad_stack[:, c_off:c_off+10]``.
+    ``deterministic``: the neighbours' gradients go through the atomics-free sorted scatter instead of fp32 atomics."""
+    _int(idx, "idx"); _gpu(grad_stack, centre_xyz, src_xyz, idx)
+    B, S, K = idx.shape
+    N = src_xyz.shape[2]
+    ptr, stride = _slice_ptr(grad_stack, c_off, 10)
+    dev = idx.device
+    dc = torch.empty((B, 3, S), dtype=torch.float32, device=dev) if want_centre else None
+    pairs = torch.empty((B, 3, S, K), dtype=torch.float32, device=dev) if (want_src and deterministic) else None
+    ds = torch.zeros((B, 3, N), dtype=torch.float32, device=dev) if (want_src and not deterministic) else None
+    if dc is not None or ds is not None or pairs is not None:
+        p0 = lambda t: _p(t) if t is not None else 0
+        _lib.call("geometry_encode_grad_kernel_wrapper", dev, B, N, S, K, _p(centre_xyz), _p(src_xyz), _p(idx), ptr, stride,
+                  p0(dc), p0(ds), p0(pairs))
+    if pairs is not None:
+        ds = group_points_grad_from(pairs, 0, 3, idx, N, deterministic=True, inverse=inverse)
+    return dc, ds
+
+
+def broadcast_centre_into(feats, k, stack, c_off):
+    """``stack[:, c_off:c_off+C] = feats.unsqueeze(3).expand(-1, -1, -1, k)`` (feats (B,C,S))."""
+    _float(feats, "feats"); _gpu(feats, stack)
+    B, C, S = feats.shape
+    if tuple(stack.shape[0:1] + stack.shape[2:]) != (B, S, k):
+        raise ValueError("broadcast_centre: feats %s stack %s k %d" % (tuple(feats.shape), tuple(stack.shape), k))
+    ptr, stride = _slice_ptr(stack, c_off, C)
+    _lib.call("broadcast_centre_kernel_wrapper", feats.device, B, C, S, k, _p(feats), ptr, stride)
+
+
+def broadcast_centre_grad_from(grad_stack, c_off, c):
+    """``grad_stack[:, c_off:c_off+c].sum(3)`` without the slice copy."""
+    _gpu(grad_stack)
+    B, _, S, K = grad_stack.shape
+    ptr, stride = _slice_ptr(grad_stack, c_off, c)
+    out = torch.empty((B, c, S), dtype=torch.float32, device=grad_stack.device)
+    _lib.call("broadcast_centre_grad_kernel_wrapper", grad_stack.device, B, c, S, K, ptr, stride, _p(out))
+    return out
+
+
 # ---- native replacements of pure-PyTorch ops (include/pwclo_ops.h section 2) ---------------------
 
 _KNN_MIN_S = int(_os.environ.get("PWCLO_KNN_MIN_S", "256"))     # fewer queries: the exhaustive kernel (no build pass)

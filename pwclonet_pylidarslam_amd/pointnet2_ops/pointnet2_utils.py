@@ -171,53 +171,82 @@ grouping_operation = GroupingOperation.apply
 
 
 class GroupConcat(Function):
-    """``torch.cat([part_0, part_1, ...], dim=1)`` of a shared MLP's input where some parts are
-    ``grouping_operation(features, idx)``: those are grouped by the kernel straight into their channel slice of the
-    result, and in backward their gradient is scattered straight out of the slice of the incoming gradient (the
-    reference writes the grouped tensor and copies it again in ``torch.cat``: P2/pointnet2_modules.py:222-230, 490-500,
-    PW/costvolume.py:134, 172).  Same values, two copies of the grouped tensor fewer each way."""
+    """``torch.cat([part_0, part_1, ...], dim=1)`` of a shared MLP's input, every part written by its own kernel straight
+    into its channel slice of the result, and differentiated straight out of the slice of the incoming gradient:
+      "g"   ``grouping_operation(features (B,C,N), idx)``   (P2/pointnet2_modules.py:222-230, 490-500, PW/costvolume.py:134, 172)
+      "c"   centre features (B,C,S) tiled over the K neighbours   (PW/costvolume.py:95, 158: torch.tile)
+      "geo" the 10-channel geometry encoding of (centre_xyz (B,3,S), src_xyz (B,3,N)) pairs   (PW/costvolume.py:92-105)
+      "t"   any dense (B,C,S,K) tensor (may be an expanded view): one strided copy.
+    The reference writes every part as its own tensor and copies it again in ``torch.cat``.  Same values."""
+
+    ARITY = {"g": 1, "c": 1, "t": 1, "geo": 2}
 
     @staticmethod
     def forward(ctx, idx, kinds, *tensors):
         B, S, K = idx.shape
-        chans = [t.shape[1] for t in tensors]
+        parts, pos = [], 0
+        for kind in kinds:
+            ts = tensors[pos:pos + GroupConcat.ARITY[kind]]
+            parts.append((kind, pos, ts, 10 if kind == "geo" else ts[0].shape[1]))
+            pos += len(ts)
         ref = tensors[0]
-        out = torch.empty((B, sum(chans), S, K), dtype=ref.dtype, device=ref.device)
+        out = torch.empty((B, sum(p[3] for p in parts), S, K), dtype=ref.dtype, device=ref.device)
         off = 0
-        for kind, t, c in zip(kinds, tensors, chans):
+        saved = [idx]
+        for kind, _, ts, c in parts:
             if kind == "g":
-                _ext.group_points_into(t.contiguous(), idx, out, off)
+                _ext.group_points_into(ts[0].contiguous(), idx, out, off)
+            elif kind == "c":
+                _ext.broadcast_centre_into(ts[0].contiguous(), K, out, off)
+            elif kind == "geo":
+                cx, sx = ts[0].contiguous(), ts[1].contiguous()
+                _ext.geometry_encode_into(cx, sx, idx, out, off)
+                saved += [cx, sx]
             else:
-                out[:, off:off + c].copy_(t)          # dense part (may be an expanded view: one strided copy)
+                out[:, off:off + c].copy_(ts[0])          # dense part (may be an expanded view: one strided copy)
             off += c
-        ctx.save_for_backward(idx)
-        ctx.kinds, ctx.chans = kinds, chans
-        ctx.ns = [t.shape[2] for t in tensors]
+        ctx.save_for_backward(*saved)
+        ctx.parts = [(kind, pos, c, [t.shape[2] for t in ts]) for kind, pos, ts, c in parts]
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        (idx,) = ctx.saved_tensors
+        idx = ctx.saved_tensors[0]
+        geo_saved = list(ctx.saved_tensors[1:])
         g = grad_out.contiguous()
         det = deterministic_grads()
         inverse = {}
-        grads, off = [], 0
-        for i, (kind, c, n) in enumerate(zip(ctx.kinds, ctx.chans, ctx.ns)):
-            if not ctx.needs_input_grad[2 + i]:
-                grads.append(None)
+        grads = [None] * sum(GroupConcat.ARITY[p[0]] for p in ctx.parts)
+        off = 0
+        for kind, pos, c, ns in ctx.parts:
+            need = [ctx.needs_input_grad[2 + pos + a] for a in range(GroupConcat.ARITY[kind])]
+            if kind == "geo":
+                cx, sx = geo_saved.pop(0), geo_saved.pop(0)
+                if any(need):
+                    n = ns[1]
+                    if det and need[1] and n not in inverse:
+                        inverse[n] = _ext._inverse_index(idx, n)
+                    grads[pos], grads[pos + 1] = _ext.geometry_encode_grad_from(g, off, cx, sx, idx, need[0], need[1],
+                                                                                 deterministic=det, inverse=inverse.get(n))
+            elif not need[0]:
+                pass
             elif kind == "g":
+                n = ns[0]
                 if det and n not in inverse:
                     inverse[n] = _ext._inverse_index(idx, n)
-                grads.append(_ext.group_points_grad_from(g, off, c, idx, n, deterministic=det, inverse=inverse.get(n)))
+                grads[pos] = _ext.group_points_grad_from(g, off, c, idx, n, deterministic=det, inverse=inverse.get(n))
+            elif kind == "c":
+                grads[pos] = _ext.broadcast_centre_grad_from(g, off, c)
             else:
-                grads.append(g[:, off:off + c])
+                grads[pos] = g[:, off:off + c]
             off += c
         return (None, None) + tuple(grads)
 
 
 def group_concat(idx, *parts):
-    """parts: ``("g", features (B,C,N))`` = grouped by idx, or ``("t", tensor (B,C,S,K))``; -> (B, sum C, S, K)."""
-    return GroupConcat.apply(idx, tuple(k for k, _ in parts), *[t for _, t in parts])
+    """parts: ``("g", features (B,C,N))``, ``("c", centre features (B,C,S))``, ``("geo", centre_xyz (B,3,S), src_xyz
+    (B,3,N))`` or ``("t", tensor (B,C,S,K))`` (see ``GroupConcat``); -> (B, sum C, S, K)."""
+    return GroupConcat.apply(idx, tuple(p[0] for p in parts), *[t for p in parts for t in p[1:]])
 
 
 class BallQuery(Function):

@@ -8,15 +8,6 @@ from ..pointnet2_ops import pytorch_utils as pt_utils
 from ..softmax_wsum import softmax_weighted_sum
 
 
-def _geometry(centre_xyz, grouped_xyz):
-    """10-channel geometry encoding [p, q, q-p, |q-p|] (costvolume.py:92-105); centre_xyz
-    (B,3,S), grouped_xyz (B,3,S,K) -> (B,10,S,K)."""
-    p = centre_xyz.unsqueeze(3).expand_as(grouped_xyz)
-    diff = grouped_xyz - p
-    euc = torch.sqrt(torch.sum(torch.square(diff), dim=1, keepdim=True) + 1e-20)
-    return torch.cat((p, grouped_xyz, diff, euc), dim=1)
-
-
 class CostVolume(nn.Module):
     """(warped_xyz (B,3,S), warped_points (B,C1,S), f2_xyz (B,3,N), f2_points (B,C2,N))
     -> (B, mlp2[-1], S).  Requires mlp1[-1] == mlp2[-1]."""
@@ -40,22 +31,19 @@ class CostVolume(nn.Module):
         warped_xyz_t = warped_xyz.permute(0, 2, 1).contiguous()
         f2_xyz_t = f2_xyz.permute(0, 2, 1).contiguous()
         kq, k = self.nsample_q, self.nsample
+        gc = pointutils.group_concat
 
-        # first aggregate: frame-2 neighbours of every (warped) frame-1 point
+        # first aggregate: frame-2 neighbours of every (warped) frame-1 point.  cat((geometry, tiled centre features,
+        # grouped frame-2 features)) and the geometry alone, every part written by its own kernel (no tile / sub / square
+        # / sum / sqrt / cat chain, forward or backward)
         _, idx_q = pt_utils.knn_point(kq, f2_xyz_t, warped_xyz_t)
-        q_xyz = pointutils.grouping_operation(f2_xyz.contiguous(), idx_q)
-        geo = _geometry(warped_xyz, q_xyz)
-        p_pts = warped_points.unsqueeze(3).expand(-1, -1, -1, kq)
-        # cat((geo, p_pts, grouped frame-2 features)): the grouping kernel writes its slice of the result directly
-        feat = self.mlp_convs(pointutils.group_concat(idx_q, ("t", geo), ("t", p_pts), ("g", f2_points)))
-        enc = self.mlp_conv_xyz_1(geo)
+        feat = self.mlp_convs(gc(idx_q, ("geo", warped_xyz, f2_xyz), ("c", warped_points), ("g", f2_points)))
+        enc = self.mlp_conv_xyz_1(gc(idx_q, ("geo", warped_xyz, f2_xyz)))
         # softmax over the neighbours + weighted sum (costvolume.py:139-141) as one kernel each way on the GPU
         first = softmax_weighted_sum(self.mlp2_convs(torch.cat((enc, feat), dim=1)), feat)
 
         # second aggregate: frame-1 neighbours of every frame-1 point
         _, idx = pt_utils.knn_point(k, warped_xyz_t, warped_xyz_t)
-        c_xyz = pointutils.grouping_operation(warped_xyz.contiguous(), idx)
         c_pts = pointutils.grouping_operation(first.contiguous(), idx)
-        enc2 = self.mlp_conv_xyz_2(_geometry(warped_xyz, c_xyz))
-        p_pts2 = warped_points.unsqueeze(3).expand(-1, -1, -1, k)
-        return softmax_weighted_sum(self.mlp3_convs(torch.cat((enc2, p_pts2, c_pts), dim=1)), c_pts)   # :181-183
+        enc2 = self.mlp_conv_xyz_2(gc(idx, ("geo", warped_xyz, warped_xyz)))
+        return softmax_weighted_sum(self.mlp3_convs(gc(idx, ("t", enc2), ("c", warped_points), ("t", c_pts))), c_pts)   # :181-183

@@ -576,6 +576,72 @@ def test_group_concat_equals_cat_of_grouped(cuda, b, c, n, s, k):
         E.group_points_into(g(feat, cuda), g(idx, cuda), torch.empty(b, c, s, k, device=cuda), 1)
 
 
+@pytest.mark.parametrize("b,n,s,k,c1,c2,same", [(2, 500, 300, 6, 16, 8, False), (3, 256, 256, 4, 64, 64, True), (1, 64, 33, 5, 3, 1, False),
+                                                 (2, 2048, 2048, 6, 32, 32, False), (2, 40, 40, 32, 128, 7, True)])
+def test_cost_volume_inputs_as_parts_of_the_concatenation(cuda, b, n, s, k, c1, c2, same):
+    """group_concat parts "geo" (the 10-channel geometry encoding of PW/costvolume.py:92-105) and "c" (torch.tile of the
+    centre features, :95) against the reference's chain of torch ops evaluated by torch on the GPU: forward bit for bit
+    (same fp32 expressions, no fused multiply-add), backward against a float64 evaluation of the same chain at 1e-5 of
+    each gradient's scale -- including the second aggregate's case where centres and neighbours are the same cloud
+    (``same``: both roles receive a gradient and autograd adds them)."""
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pointnet2_utils as PU
+    gen = torch.Generator().manual_seed(b * 31 + n + k)
+    src = torch.randn(b, 3, n, generator=gen) * 10
+    centre = src.clone() if same else torch.randn(b, 3, s, generator=gen) * 10
+    assert centre.shape[2] == s
+    idx = torch.randint(0, n, (b, s, k), generator=gen, dtype=torch.int32)
+    if same:
+        idx[:, :, 0] = torch.arange(s, dtype=torch.int32)          # the point itself: |q - p| = sqrt(1e-20)
+    pf = torch.randn(b, c1, s, generator=gen)
+    qf = torch.randn(b, c2, n, generator=gen)
+    go = torch.randn(b, 10 + c1 + c2, s, k, generator=gen)
+
+    def chain(cx, sx, pfeat, qfeat, dt):
+        gather = lambda t: torch.gather(t.unsqueeze(2).expand(-1, -1, s, -1), 3,
+                                        idx.to(t.device).long().unsqueeze(1).expand(-1, t.shape[1], -1, -1))
+        q = gather(sx)
+        p = cx.unsqueeze(3).expand(-1, -1, -1, k)
+        diff = q - p
+        euc = torch.sqrt(torch.sum(torch.square(diff), dim=1, keepdim=True) + 1e-20)
+        return torch.cat((p, q, diff, euc, pfeat.unsqueeze(3).expand(-1, -1, -1, k), gather(qfeat)), dim=1)
+
+    want = chain(centre.to(cuda), src.to(cuda), pf.to(cuda), qf.to(cuda), torch.float32)
+    l64 = [t.double().requires_grad_(True) for t in ((centre,) if same else (centre, src))] + \
+          [pf.double().requires_grad_(True), qf.double().requires_grad_(True)]
+    c64, s64 = (l64[0], l64[0]) if same else (l64[0], l64[1])
+    chain(c64, s64, l64[-2], l64[-1], torch.float64).backward(go.double())
+
+    def run():
+        leaves = [t.to(cuda).requires_grad_(True) for t in ((centre,) if same else (centre, src))] + \
+                 [pf.to(cuda).requires_grad_(True), qf.to(cuda).requires_grad_(True)]
+        cx, sx = (leaves[0], leaves[0]) if same else (leaves[0], leaves[1])
+        got = PU.group_concat(g(idx, cuda), ("geo", cx, sx), ("c", leaves[-2]), ("g", leaves[-1]))
+        assert torch.equal(got, want)
+        got.backward(go.to(cuda))
+        return [t.grad for t in leaves]
+
+    for det in (False, True):                  # fp32 atomics / the atomics-free sorted scatter
+        PU.deterministic_grads(det)
+        try:
+            grads = run()
+            for a_, r_ in zip(grads, l64):
+                scale = r_.grad.abs().max().item()
+                assert (a_.cpu().double() - r_.grad).abs().max().item() <= 1e-5 * scale + 1e-12, (a_.shape, scale, det)
+            if det:
+                for a_, b_ in zip(grads, run()):
+                    assert torch.equal(a_, b_)
+        finally:
+            PU.deterministic_grads(False)
+    # gradient not wanted for the neighbour coordinates (the pyramid's clouds): no scatter, same centre gradient
+    cx2 = centre.to(cuda).requires_grad_(True)
+    PU.group_concat(g(idx, cuda), ("geo", cx2, src.to(cuda))).backward(go[:, :10].contiguous().to(cuda))
+    if not same:
+        cx3 = centre.to(cuda).requires_grad_(True)
+        sx3 = src.to(cuda).requires_grad_(True)
+        PU.group_concat(g(idx, cuda), ("geo", cx3, sx3)).backward(go[:, :10].contiguous().to(cuda))
+        assert torch.equal(cx2.grad, cx3.grad)
+
+
 @pytest.mark.parametrize("shape", [(4, 8, 300, 7), (8, 16, 2048, 32), (2, 64, 1, 5), (3, 5, 1000), (32, 128, 64, 8)])
 @pytest.mark.parametrize("affine,relu", [(True, False), (False, False), (True, True)])
 def test_batchnorm_train_kernels(cuda, shape, affine, relu):
