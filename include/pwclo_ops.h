@@ -344,6 +344,11 @@ void geometry_encode_kernel_wrapper(int b, int n, int s, int k, const float *cen
 void geometry_encode_grad_kernel_wrapper(int b, int n, int s, int k, const float *centre_xyz, const float *src_xyz,
                                          const int *idx, const float *grad_out, long long batch_stride,
                                          float *d_centre_xyz, float *d_src_xyz, float *d_pair);
+/* out[b, 0:3, j, t] = src_xyz[b, :, idx[b,j,t]] - centre_xyz[b, :, j] (P2/pointnet2_modules.py:215-218, 485-488), into a
+ * channel slice like the entries above; its gradient is group_points_grad_strided (neighbours) and minus
+ * broadcast_centre_grad (centres) of the same slice. */
+void xyz_diff_kernel_wrapper(int b, int n, int s, int k, const float *centre_xyz, const float *src_xyz, const int *idx,
+                             float *out, long long batch_stride);
 void broadcast_centre_kernel_wrapper(int b, int c, int s, int k, const float *feats, float *out, long long batch_stride);
 void broadcast_centre_grad_kernel_wrapper(int b, int c, int s, int k, const float *grad_out, long long batch_stride,
                                           float *d_feats);

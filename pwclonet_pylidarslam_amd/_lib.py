@@ -83,6 +83,7 @@ SIGNATURES = {
     "batchnorm_train_relu_maxk_apply_kernel_wrapper": ([_i, _i, _i, _i] + [_F] * 8, None),
     "conv1x1_wgrad_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F], None),
     "group_points_grad_sorted_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, _F, _F, _F], None),
+    "xyz_diff_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F, ctypes.c_longlong], None),
     "geometry_encode_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F, ctypes.c_longlong], None),
     "geometry_encode_grad_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, _F, _F, ctypes.c_longlong, _F, _F, _F], None),
     "broadcast_centre_kernel_wrapper": ([_i, _i, _i, _i, _F, _F, ctypes.c_longlong], None),

@@ -263,6 +263,24 @@ __global__ __launch_bounds__(GEO_THREADS) void geometry_encode_kernel(int n, int
   o[(size_t)9 * P] = e;
 }
 
+// out[b, 0:3, j, t] = src[b, :, idx[b, j, t]] - centre[b, :, j]: the grouped coordinates relative to their centre
+// (P2/pointnet2_modules.py:215-218, 485-488: grouping_operation, then the subtraction of the tiled centres).
+__global__ __launch_bounds__(GEO_THREADS) void xyz_diff_kernel(int n, int s, int k, const float *__restrict__ centre,
+                                                               const float *__restrict__ src, const int *__restrict__ idx,
+                                                               float *__restrict__ out, long long bstride) {
+  const int b = blockIdx.y;
+  const int P = s * k;
+  const int p = blockIdx.x * GEO_THREADS + threadIdx.x;
+  if (p >= P) return;
+  const int j = p / k;
+  const int i = idx[(size_t)b * P + p];
+  const float *c = centre + (size_t)b * 3 * s, *q = src + (size_t)b * 3 * n;
+  float *o = out + (size_t)b * bstride + p;
+  o[0] = q[i] - c[j];
+  o[(size_t)P] = q[n + i] - c[s + j];
+  o[(size_t)2 * P] = q[2 * n + i] - c[2 * s + j];
+}
+
 // One thread per centre: the K neighbour gradients of a centre are consecutive.  d_centre (B, 3, S) is written (the sum over
 // the centre's K pairs, in neighbour order: deterministic); d_src (B, 3, N), when wanted, is zero-filled by the caller and
 // receives atomic adds (or none at all: the pyramid's coordinates need no gradient); d_pair (B, 3, S, K) instead takes the
@@ -545,4 +563,14 @@ extern "C" void broadcast_centre_grad_kernel_wrapper(int b, int c, int s, int k,
   hipLaunchKernelGGL(broadcast_centre_grad_kernel, dim3(ceil_div(s, GEO_THREADS), c, b), dim3(GEO_THREADS), 0, current_stream(), c,
                      s, k, grad_out, batch_stride, d_feats);
   check_launch("broadcast_centre_grad");
+}
+
+extern "C" void xyz_diff_kernel_wrapper(int b, int n, int s, int k, const float *centre_xyz, const float *src_xyz, const int *idx,
+                                        float *out, long long batch_stride) {
+  if (b <= 0 || s <= 0 || k <= 0) return;
+  PWCLO_REQUIRE(n > 0 && b <= 65535 && (long long)s * k < (1ll << 31), "xyz_diff: b=%d n=%d s*k=%lld out of range", b, n,
+                (long long)s * k);
+  hipLaunchKernelGGL(xyz_diff_kernel, dim3(ceil_div(s * k, GEO_THREADS), b), dim3(GEO_THREADS), 0, current_stream(), n, s, k,
+                     centre_xyz, src_xyz, idx, out, batch_stride);
+  check_launch("xyz_diff");
 }

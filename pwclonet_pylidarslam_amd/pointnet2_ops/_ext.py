@@ -296,6 +296,17 @@ def geometry_encode_into(centre_xyz, src_xyz, idx, stack, c_off):
               stride)
 
 
+def xyz_diff_into(centre_xyz, src_xyz, idx, stack, c_off):
+    """``stack[:, c_off:c_off+3] = group_points(src_xyz, idx) - centre_xyz.unsqueeze(3)`` (centre_xyz (B,3,S), src_xyz (B,3,N))."""
+    _float(centre_xyz, "centre_xyz"); _float(src_xyz, "src_xyz"); _int(idx, "idx"); _gpu(centre_xyz, src_xyz, idx, stack)
+    B, S, K = idx.shape
+    if centre_xyz.shape != (B, 3, S) or src_xyz.shape[:2] != (B, 3) or tuple(stack.shape[0:1] + stack.shape[2:]) != (B, S, K):
+        raise ValueError("xyz_diff: centre %s src %s idx %s stack %s" % (tuple(centre_xyz.shape), tuple(src_xyz.shape),
+                                                                          tuple(idx.shape), tuple(stack.shape)))
+    ptr, stride = _slice_ptr(stack, c_off, 3)
+    _lib.call("xyz_diff_kernel_wrapper", idx.device, B, src_xyz.shape[2], S, K, _p(centre_xyz), _p(src_xyz), _p(idx), ptr, stride)
+
+
 def geometry_encode_grad_from(grad_stack, c_off, centre_xyz, src_xyz, idx, want_centre=True, want_src=True,
                               deterministic=False, inverse=None):
     """-> (d_centre_xyz (B,3,S) or None, d_src_xyz (B,3,N) or None) from ``grad_stack[:, c_off:c_off+10]``.

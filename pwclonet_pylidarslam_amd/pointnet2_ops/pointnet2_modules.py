@@ -152,11 +152,9 @@ class PointnetSAModulePWCLONet(nn.Module):
         if new_xyz is None:
             new_xyz = pointnet2_utils.sample_and_gather(xyz, self.npoint)   # == furthest_point_sample + gather_operation
         _, idx_q = pt_utils.knn_point(self.nsample, xyz, new_xyz)
-        grouped_xyz = pointnet2_utils.grouping_operation(xyz_flipped, idx_q)
-        xyz_diff = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
-        # cat((xyz_diff, grouped features)) with the grouping kernel writing its channel slice of the result directly
+        # cat((grouped xyz - centre, grouped features)), every part written by its own kernel into its channel slice
         new_features = pointnet2_utils.group_concat(
-            idx_q, ("t", xyz_diff), ("g", features if features is not None else xyz_flipped))
+            idx_q, ("diff", new_xyz.transpose(1, 2), xyz_flipped), ("g", features if features is not None else xyz_flipped))
         new_features = pt_utils.shared_mlp_max(self.mlp_module, new_features)  # mlp, then max_pool2d(kernel=[1,K])
         return new_xyz, new_features
 
@@ -182,10 +180,9 @@ class PointnetFPModulePWCLONet(nn.Module):
                 features1: torch.Tensor) -> torch.Tensor:
         if self.knn:
             _, idx_q = pt_utils.knn_point(self.nsample, xyz1, xyz2)
-            grouped_xyz = pointnet2_utils.grouping_operation(xyz1.transpose(1, 2).contiguous(), idx_q)
-            xyz_diff = grouped_xyz - xyz2.transpose(1, 2).unsqueeze(-1)
             if self.use_xyz:
-                new_features = pointnet2_utils.group_concat(idx_q, ("g", features1), ("t", xyz_diff))
+                new_features = pointnet2_utils.group_concat(idx_q, ("g", features1),
+                                                            ("diff", xyz2.transpose(1, 2), xyz1.transpose(1, 2)))
             else:
                 new_features = pointnet2_utils.grouping_operation(features1, idx_q)
         else:

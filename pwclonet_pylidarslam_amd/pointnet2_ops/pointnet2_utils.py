@@ -176,10 +176,13 @@ class GroupConcat(Function):
       "g"   ``grouping_operation(features (B,C,N), idx)``   (P2/pointnet2_modules.py:222-230, 490-500, PW/costvolume.py:134, 172)
       "c"   centre features (B,C,S) tiled over the K neighbours   (PW/costvolume.py:95, 158: torch.tile)
       "geo" the 10-channel geometry encoding of (centre_xyz (B,3,S), src_xyz (B,3,N)) pairs   (PW/costvolume.py:92-105)
+      "diff" grouped coordinates relative to their centres, (centre_xyz (B,3,S), src_xyz (B,3,N)) -> 3 channels
+            (P2/pointnet2_modules.py:215-218, 485-488: grouping_operation minus the tiled centres)
       "t"   any dense (B,C,S,K) tensor (may be an expanded view): one strided copy.
     The reference writes every part as its own tensor and copies it again in ``torch.cat``.  Same values."""
 
-    ARITY = {"g": 1, "c": 1, "t": 1, "geo": 2}
+    ARITY = {"g": 1, "c": 1, "t": 1, "geo": 2, "diff": 2}
+    CHANNELS = {"geo": 10, "diff": 3}
 
     @staticmethod
     def forward(ctx, idx, kinds, *tensors):
@@ -187,7 +190,7 @@ class GroupConcat(Function):
         parts, pos = [], 0
         for kind in kinds:
             ts = tensors[pos:pos + GroupConcat.ARITY[kind]]
-            parts.append((kind, pos, ts, 10 if kind == "geo" else ts[0].shape[1]))
+            parts.append((kind, pos, ts, GroupConcat.CHANNELS.get(kind) or ts[0].shape[1]))
             pos += len(ts)
         ref = tensors[0]
         out = torch.empty((B, sum(p[3] for p in parts), S, K), dtype=ref.dtype, device=ref.device)
@@ -202,6 +205,8 @@ class GroupConcat(Function):
                 cx, sx = ts[0].contiguous(), ts[1].contiguous()
                 _ext.geometry_encode_into(cx, sx, idx, out, off)
                 saved += [cx, sx]
+            elif kind == "diff":
+                _ext.xyz_diff_into(ts[0].contiguous(), ts[1].contiguous(), idx, out, off)
             else:
                 out[:, off:off + c].copy_(ts[0])          # dense part (may be an expanded view: one strided copy)
             off += c
@@ -228,6 +233,14 @@ class GroupConcat(Function):
                         inverse[n] = _ext._inverse_index(idx, n)
                     grads[pos], grads[pos + 1] = _ext.geometry_encode_grad_from(g, off, cx, sx, idx, need[0], need[1],
                                                                                  deterministic=det, inverse=inverse.get(n))
+            elif kind == "diff":
+                if need[0]:
+                    grads[pos] = _ext.broadcast_centre_grad_from(g, off, 3).neg_()
+                if need[1]:
+                    n = ns[1]
+                    if det and n not in inverse:
+                        inverse[n] = _ext._inverse_index(idx, n)
+                    grads[pos + 1] = _ext.group_points_grad_from(g, off, 3, idx, n, deterministic=det, inverse=inverse.get(n))
             elif not need[0]:
                 pass
             elif kind == "g":
@@ -244,8 +257,8 @@ class GroupConcat(Function):
 
 
 def group_concat(idx, *parts):
-    """parts: ``("g", features (B,C,N))``, ``("c", centre features (B,C,S))``, ``("geo", centre_xyz (B,3,S), src_xyz
-    (B,3,N))`` or ``("t", tensor (B,C,S,K))`` (see ``GroupConcat``); -> (B, sum C, S, K)."""
+    """parts: ``("g", features (B,C,N))``, ``("c", centre features (B,C,S))``, ``("geo" | "diff", centre_xyz (B,3,S),
+    src_xyz (B,3,N))`` or ``("t", tensor (B,C,S,K))`` (see ``GroupConcat``); -> (B, sum C, S, K)."""
     return GroupConcat.apply(idx, tuple(p[0] for p in parts), *[t for p in parts for t in p[1:]])
 
 

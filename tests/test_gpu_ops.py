@@ -642,6 +642,31 @@ def test_cost_volume_inputs_as_parts_of_the_concatenation(cuda, b, n, s, k, c1, 
         assert torch.equal(cx2.grad, cx3.grad)
 
 
+@pytest.mark.parametrize("b,n,s,k", [(2, 500, 300, 8), (1, 64, 33, 5), (2, 8192, 2048, 32)])
+def test_grouped_coordinates_relative_to_their_centres_as_a_part(cuda, b, n, s, k):
+    """group_concat part "diff" = grouping_operation(xyz) - centres (P2/pointnet2_modules.py:215-218, 485-488): forward bit
+    for bit against the two torch ops, both gradients (fp32 atomics and the atomics-free scatter) against the oracle's
+    group_points_grad / a float64 sum."""
+    from pwclonet_pylidarslam_amd.pointnet2_ops import pointnet2_utils as PU
+    gen = torch.Generator().manual_seed(b + n + k)
+    src = torch.randn(b, 3, n, generator=gen) * 10
+    centre = torch.randn(b, 3, s, generator=gen) * 10
+    idx = torch.randint(0, n, (b, s, k), generator=gen, dtype=torch.int32)
+    go = torch.randn(b, 3, s, k, generator=gen)
+    want = O.group_points(src, idx) - centre.unsqueeze(3)
+    for det in (False, True):
+        PU.deterministic_grads(det)
+        try:
+            cx, sx = centre.to(cuda).requires_grad_(True), src.to(cuda).requires_grad_(True)
+            got = PU.group_concat(g(idx, cuda), ("diff", cx, sx))
+            assert torch.equal(got.cpu(), want)
+            got.backward(go.to(cuda))
+            torch.testing.assert_close(sx.grad.cpu(), O.group_points_grad(go, idx, n), rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(cx.grad.cpu().double(), -go.double().sum(3), rtol=1e-5, atol=1e-5)
+        finally:
+            PU.deterministic_grads(False)
+
+
 @pytest.mark.parametrize("shape", [(4, 8, 300, 7), (8, 16, 2048, 32), (2, 64, 1, 5), (3, 5, 1000), (32, 128, 64, 8)])
 @pytest.mark.parametrize("affine,relu", [(True, False), (False, False), (True, True)])
 def test_batchnorm_train_kernels(cuda, shape, affine, relu):
