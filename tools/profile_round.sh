@@ -9,6 +9,16 @@ mkdir -p $out
 # whatever happens, leave only small files behind (gpurun copies back at most 64 MiB)
 trap 'find $out -name "*.db" -delete; find $out -name "*kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete; find $out -name "*agent_info.csv" -delete' EXIT
 export TMPDIR=/tmp
+# PMC passes FIRST (separate runs, counters only), and their stamped summaries into profiles/ of this tree, so that the bench
+# lines below report the traffic / matrix-pipe figures of the code they time (bench.py prints traffic_stale otherwise)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
+python tools/pmc_traffic.py "$(find $out/fetch -name '*counter_collection.csv' | head -1)" \
+       "$(find $out/write -name '*counter_collection.csv' | head -1)" -o $out/pmc_traffic.json
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out/sq -o sq -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
+python tools/pmc_mfma.py "$(find $out/sq -name '*counter_collection.csv' | head -1)" -o $out/pmc_mfma_busy.json > $out/pmc_mfma_busy.txt
+cp $out/pmc_traffic.json $out/pmc_mfma_busy.json profiles/
+find $out -name "*counter_collection.csv" -delete
 python bench.py > $out/${tag}_default_bench.json
 python bench.py --config 5 --no-configs > $out/${tag}_config5_bench.json
 python bench.py --config 5 --config5-inflight 1 --no-cpu-baseline --no-configs > $out/${tag}_config5_one_in_flight_bench.json
@@ -24,16 +34,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/eager -o eager -- p
 # libpwclo_hip.so that runs at exit() is the compiler-generated __hip_module_dtor -> __hipUnregisterFatBinary, after the
 # tool has already torn the runtime down): the exit status is ignored, the kernel statistics are what is kept.
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5 -o c5 -- python bench.py --config 5 --config5-inflight 1 --no-cpu-baseline --no-configs > $out/${tag}_config5_coop_under_rocprof.json 2> $out/rocprof_c5.err || echo "config-5 rocprof pass: exit status $? (see rocprof_c5.err; the statistics file is checked below)"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
-find $out -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | sort
+find $out -name "*kernel_stats.csv" | sort
 cp "$(find $out/default -name '*kernel_stats.csv' | head -1)" $out/${tag}_default_bench_kernel_stats.csv
 cp "$(find $out/eager -name '*kernel_stats.csv' | head -1)" $out/${tag}_eager_inflight1_kernel_stats.csv
 cp "$(find $out/c5 -name '*kernel_stats.csv' | head -1)" $out/${tag}_config5_kernel_stats.csv || true
-python tools/pmc_traffic.py "$(find $out/fetch -name '*counter_collection.csv' | head -1)" \
-       "$(find $out/write -name '*counter_collection.csv' | head -1)" -o $out/pmc_traffic.json
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out/sq -o sq -- python tools/launch_table.py --reps 1 > /dev/null 2>&1
-python tools/pmc_mfma.py "$(find $out/sq -name '*counter_collection.csv' | head -1)" -o $out/pmc_mfma_busy.json > $out/pmc_mfma_busy.txt
 # training step of configs[3]'s per-GPU share: eager and graphed throughput, per-layer convolution table,
 # rocprofv3 kernel summary
 python tools/train_step.py --batch 32 --steps 10 --warmup 3 --fused-adam > $out/${tag}_train_step_b32.jsonl 2> /dev/null
