@@ -511,7 +511,20 @@ static ConvGrid conv_grid(int b, int cin, int cout, int p, bool stats) {
   cg.nbi = ceil_div(cin, 16);
   const int nbo_all = ceil_div(cout, 16);
   cg.gy = ceil_div(nbo_all, CONV_MAX_NBO);                              // groups of output blocks (input re-read per group)
+  // Few pixels (the coarse pyramid levels: 64 ... 2048 pixels per cloud): one 32-pixel tile per wave does not fill the chip,
+  // and a wave that owns all 8 output blocks of a 192-channel layer issues 768 dependent-rate MFMAs (10 us) after its
+  // workgroup has packed 96 KiB of weights.  Split the output channels over more workgroups instead -- narrower weight
+  // slices, the (L2-resident) input tile re-read per group -- until the launch has at least half a workgroup per CU.  Same k order per
+  // output element: bit-identical results.  (tools/conv_table.py: 40 -> ~15 us for 192 -> 128 channels at 64 pixels.)
+  {
+    const long long one_tile_per_wave = (( (long long)b * ceil_div(p, 32)) + CONV_WAVES - 1) / CONV_WAVES;
+    static int split_env = -1;
+    if (split_env < 0) { const char *e = getenv("PWCLO_CONV_SPLIT"); split_env = e ? atoi(e) : 1; }
+    // (measured: worth it while the launch is under HALF a workgroup per CU; at 192 of 256 the split only adds input re-reads)
+    while (split_env && cg.gy < nbo_all && 2 * one_tile_per_wave * cg.gy <= conv_grid_x()) cg.gy = min(nbo_all, cg.gy * 2);
+  }
   cg.nbo = ceil_div(nbo_all, cg.gy);
+  cg.gy = ceil_div(nbo_all, cg.nbo);
   cg.lds = (size_t)cg.nbo * cg.nbi * WAVE * sizeof(float4) + (size_t)cg.nbi * 16 * sizeof(float4);   // weights + input transform
   if (stats) cg.lds += (size_t)CONV_WAVES * cg.nbo * 16 * 2 * sizeof(double);                        // + the waves' fp64 slots
   const long long tiles = (long long)b * ceil_div(p, 32);

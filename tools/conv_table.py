@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: every pointwise-convolution call of one training step (shape, count) timed in isolation --
-forward, input gradient, weight gradient -- with the HBM and fp32-MFMA bounds beside it.
+forward (plain, and with the BatchNorm-statistics epilogue + its finish launch), input gradient, weight gradient -- with the HBM and
+fp32-MFMA bounds beside it.
 
     python tools/conv_table.py [--batch 32]
 """
@@ -46,20 +47,23 @@ def main():
     gt = torch.zeros(a.batch, 7, device=dev)
     gt[:, 3] = 1.0
     shapes = collections.Counter()
-    orig = conv1x1.conv1x1
+    orig_call = _lib.call
+    fwd_names = ("conv1x1_forward_kernel_wrapper", "conv1x1_bnrelu_forward_kernel_wrapper",
+                 "conv1x1_forward_bnstats_kernel_wrapper")
 
-    def spy(x, w):
-        shapes[(x.shape[0], x.shape[1], w.shape[0], x.numel() // (x.shape[0] * x.shape[1]))] += 1
-        return orig(x, w)
-    conv1x1.conv1x1 = spy
+    def spy(name, device, *args):          # every forward convolution of the step (B, cin, cout, pixels); dgrad calls are transposed
+        if name in fwd_names and not (name == fwd_names[0] and args[6] == 1):
+            shapes[tuple(int(v) for v in args[:4])] += 1
+        return orig_call(name, device, *args)
+    _lib.call = spy
     loss, _, _ = unit(x1, x2, gt)
+    _lib.call = orig_call
     loss.backward()
-    conv1x1.conv1x1 = orig
     torch.cuda.synchronize()
     lib = _lib.load()
-    tot = [0.0, 0.0, 0.0]
-    print("%4s %4s %4s %8s %3s | %21s | %21s | %21s" % ("B", "cin", "cout", "pixels", "n", "forward us (hbm/mfma)", "dgrad us (hbm/mfma)",
-                                                        "wgrad us (hbm/mfma)"))
+    tot = [0.0, 0.0, 0.0, 0.0]
+    print("%4s %4s %4s %8s %3s | %21s | %9s | %21s | %21s" % ("B", "cin", "cout", "pixels", "n", "forward us (hbm/mfma)", "+stats us",
+                                                              "dgrad us (hbm/mfma)", "wgrad us (hbm/mfma)"))
     for (B, cin, cout, P), n in sorted(shapes.items(), key=lambda kv: -kv[0][3] * kv[0][1] * kv[0][2]):
         x = torch.randn(B, cin, P, device=dev)
         w = torch.randn(cout, cin, device=dev)
@@ -69,16 +73,23 @@ def main():
         dw = torch.empty(cout, cin, device=dev)
         ws = torch.empty(lib.conv1x1_wgrad_workspace_bytes(B, cin, cout, P) // 4, device=dev)
         f = timed(lambda: _lib.call("conv1x1_forward_kernel_wrapper", dev, B, cin, cout, P, x.data_ptr(), w.data_ptr(), 0, y.data_ptr()))
+        sws = torch.empty(lib.conv1x1_stats_workspace_bytes(B, cin, cout, P) // 8, dtype=torch.float64, device=dev)
+        mean, invstd = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+        fs = timed(lambda: _lib.call("conv1x1_forward_bnstats_kernel_wrapper", dev, B, cin, cout, P, x.data_ptr(), w.data_ptr(), 0, 0, 0,
+                                     0, y.data_ptr(), 1e-5, 0.1, 0, 0, mean.data_ptr(), invstd.data_ptr(), sws.data_ptr()))
         d = timed(lambda: _lib.call("conv1x1_forward_kernel_wrapper", dev, B, cout, cin, P, dy.data_ptr(), w.data_ptr(), 1, dx.data_ptr()))
         g = timed(lambda: _lib.call("conv1x1_wgrad_kernel_wrapper", dev, B, cin, cout, P, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr()))
         byt = 4.0 * B * P * (cin + cout)
         fl = 2.0 * B * P * cin * cout
         bound = "%5.0f/%5.0f" % (byt / HBM * 1e6, fl / MFMA * 1e6)
-        print("%4d %4d %4d %8d %3d | %8.1f %12s | %8.1f %12s | %8.1f %12s" % (B, cin, cout, P, n, f * 1e6, bound, d * 1e6, bound, g * 1e6, bound))
+        print("%4d %4d %4d %8d %3d | %8.1f %12s | %9.1f | %8.1f %12s | %8.1f %12s" % (B, cin, cout, P, n, f * 1e6, bound, fs * 1e6, d * 1e6,
+                                                                                    bound, g * 1e6, bound))
         tot[0] += n * f
         tot[1] += n * d
         tot[2] += n * g
-    print("per step: forward %.2f ms, input gradients %.2f ms, weight gradients %.2f ms" % (tot[0] * 1e3, tot[1] * 1e3, tot[2] * 1e3))
+        tot[3] += n * fs
+    print("per step (every layer timed alone): forward %.2f ms (%.2f ms with the statistics epilogue + finish launch), input gradients "
+          "%.2f ms, weight gradients %.2f ms" % (tot[0] * 1e3, tot[3] * 1e3, tot[1] * 1e3, tot[2] * 1e3))
 
 
 if __name__ == "__main__":
