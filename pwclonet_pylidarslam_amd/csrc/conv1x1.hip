@@ -59,25 +59,30 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 
     for (int e = threadIdx.x; e < NBO * nbi * WAVE; e += CONV_THREADS) conv_w[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     const bool tr = (w_ld_o == 1);           // stored (Cin, Cout) row-major: the input-gradient view
-    const int rows = tr ? Cin : Cout, cols = tr ? Cout : Cin;
-    for (int e0 = threadIdx.x; e0 < rows * cols; e0 += 8 * CONV_THREADS) {
+    // only this workgroup's NBO output blocks: rows [16 ob0, +16 NBO) of the stored (Cout, Cin) matrix, or those COLUMNS of
+    // the (Cin, Cout) one -- a workgroup of a channel-split launch does not walk the other groups' weights
+    const int gco = min(NBO * 16, Cout - 16 * ob0);
+    const int cols = tr ? Cout : Cin;
+    const int grows = tr ? Cin : gco, gcols = tr ? gco : Cin;
+    const int total = grows * gcols;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * CONV_THREADS) {
       float v[8];
+      int rr[8], cc[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {          // 8 independent loads in flight, then the scatter
         const int e = e0 + u * CONV_THREADS;
-        v[u] = e < rows * cols ? w[e] : 0.f;
+        const int r = e / gcols, c = e - r * gcols;
+        rr[u] = r; cc[u] = c;
+        v[u] = e < total ? w[tr ? (size_t)r * cols + 16 * ob0 + c : ((size_t)16 * ob0 + r) * cols + c] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int e = e0 + u * CONV_THREADS;
-        if (e < rows * cols) {
-          const int r = e / cols, c = e - r * cols;
-          const int co = tr ? c : r, ci = tr ? r : c;
+        if (e < total) {
+          const int co = 16 * ob0 + (tr ? cc[u] : rr[u]), ci = tr ? rr[u] : cc[u];
           const int o = (co >> 4) - ob0;
-          if (o >= 0 && o < NBO) {
-            const int m = ci >> 4, s = (ci >> 2) & 3, gg = ci & 3;
-            wf[(((o * nbi + m) * WAVE) + gg * 16 + (co & 15)) * 4 + s] = v[u];
-          }
+          const int m = ci >> 4, s = (ci >> 2) & 3, gg = ci & 3;
+          wf[(((o * nbi + m) * WAVE) + gg * 16 + (co & 15)) * 4 + s] = v[u];
         }
       }
     }
