@@ -27,7 +27,7 @@ constexpr int CONV_WAVES = CONV_THREADS / WAVE;
 constexpr int CONV_MAX_NBO = 8;              // 16-channel output blocks per workgroup (128 accumulator VGPRs)
 constexpr int CONV_AHEAD = 4;               // channel blocks in flight per wave (forward / input gradient)
 constexpr int CONV_STAT_TILES = 32;        // tiles a lane adds in fp32 before its sums go to the fp64 slots
-constexpr int WGRAD_MAXV = 7;                // float4 per thread of one staged weight-gradient chunk
+constexpr int WGRAD_MAXV = 8;                // float4 per thread of one staged weight-gradient chunk
 
 // y[b][co][p] = sum_ci W(co, ci) x[b][ci][p], W(co, ci) = w[co * w_ld_o + ci * w_ld_i]  (strides: the same kernel
 // computes the input gradient with the transposed view).  P % 4 == 0, rows 16-byte aligned.  Epilogue (forward only):
@@ -455,7 +455,14 @@ static WgradPlan wgrad_plan(int b, int cin, int cout, int p) {
   }
   // chunk: as many pixels as keep the double-buffered stage under ~96 KiB, 32..512, no longer than a row
   int cp = 512;
-  while (cp > 32 && (size_t)2 * rows * (cp + 4) * 4 > (size_t)96 * 1024) cp >>= 1;
+  auto fits = [&](int c, size_t kib) {
+    return (size_t)2 * rows * (c + 4) * 4 <= kib * 1024 && (long long)rows * (c / 4) <= (long long)WGRAD_MAXV * CONV_THREADS;
+  };
+  while (cp > 32 && !fits(cp, 96)) cp >>= 1;
+  // many channels leave short chunks (256 rows: 32 pixels = one barrier per 128 MFMAs of a wave): there the stage may take
+  // 144 KiB -- measured -4 ... -10 % on the 128-channel layers (174 -> 157 us at 128 x 128 x 12 288 pixels), nothing or a
+  // lost second workgroup per CU on the narrow ones, which keep the 96 KiB rule
+  if (cp <= 64 && fits(2 * cp, 144)) cp *= 2;
   while (cp > 32 && cp / 2 >= p) cp >>= 1;
   if (cp < 16 * pl.ph) cp = 16 * pl.ph;      // every phase has at least one 16-pixel sub-chunk
   pl.cp = cp;
