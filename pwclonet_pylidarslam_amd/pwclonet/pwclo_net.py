@@ -10,7 +10,8 @@ work is scheduled:
     fast path; ``"off"`` keeps the module graph, ``prepare_fused(dtype=...)`` packs explicitly); ``train()``,
     ``load_state_dict()`` and ``.to()`` drop the packed weights again, in-place parameter edits re-pack;
   * ``log_dict`` is the reference's (host tensors, forces a D2H sync, pwclo_net.py:186-193) by
-    default; ``log_mode="device"`` keeps the same values on the GPU without a sync and
+    default -- soft-max and norm computed on the device, their result copied (the reference copies the mask and
+    computes on the host: 71 ms per batch of 32); ``log_mode="device"`` keeps the same values on the GPU without a sync and
     ``log_mode="none"`` skips them -- the benchmark states which one it used.
 """
 import torch
@@ -61,12 +62,12 @@ class LazyLogDict(dict):
                 self._ready()
                 self._ready = None
             m1, pc, to_host = self._src
+            # soft-max and norm where the mask lives, THEN the copy of the (B, N1) result: the reference copies the whole
+            # (B, C, N1) mask to the host first and runs both there -- 71 ms per batch of 32 (measured), same values up to
+            # fp32 rounding of another soft-max implementation
+            val = torch.linalg.norm(F.softmax(m1, dim=1), dim=-1, ord=2) if key == "embedding_mask" else pc
             if to_host:
-                m1, pc = m1.cpu(), pc.cpu()
-            if key == "embedding_mask":
-                val = torch.linalg.norm(F.softmax(m1, dim=1), dim=-1, ord=2)
-            else:
-                val = pc
+                val = val.cpu()
             dict.__setitem__(self, key, val)
         return dict.__getitem__(self, key)
 
@@ -262,11 +263,10 @@ class PWCLONet(nn.Module):
         if self.log_mode != "none":
             m1 = mask1.detach()
             pc = x11t.detach()
-            if self.log_mode == "host":  # reference behaviour: D2H before the softmax
-                m1, pc = m1.cpu(), pc.cpu()
-            log_dict = {"embedding_mask": torch.linalg.norm(F.softmax(m1, dim=2).permute(0, 2, 1),
-                                                            dim=-1, ord=2),
-                        "point_cloud": pc}
+            emb = torch.linalg.norm(F.softmax(m1, dim=2).permute(0, 2, 1), dim=-1, ord=2)
+            if self.log_mode == "host":  # reference behaviour: host tensors (a D2H sync inside forward) -- but the soft-max
+                emb, pc = emb.cpu(), pc.cpu()   # and norm run on the device and only their (B, N1) result is copied
+            log_dict = {"embedding_mask": emb, "point_cloud": pc}
 
         rows = [torch.cat((t, _unit(q)), dim=-1).reshape(-1, 1, 7)
                 for q, t in ((q1, t1), (q2, t2), (q3, t3), (q4, t4))]
