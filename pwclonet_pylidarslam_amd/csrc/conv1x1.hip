@@ -50,7 +50,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 
                                                               const float *__restrict__ in_invstd,
                                                               const float *__restrict__ in_gamma,
                                                               const float *__restrict__ in_beta,
-                                                              double *__restrict__ stats_partial) {
+                                                              double *__restrict__ stats_partial, unsigned x_bytes) {
   extern __shared__ float4 conv_w[];         // [NBO][nbi][64 lanes] : the 4 k-steps of one (o, m) tile per lane
   const int ob0 = blockIdx.y * NBO;
   {
@@ -65,18 +65,20 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 
     const int cols = tr ? Cout : Cin;
     const int grows = tr ? Cin : gco, gcols = tr ? gco : Cin;
     const int total = grows * gcols;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * CONV_THREADS) {
-      float v[8];
-      int rr[8], cc[8];
+    constexpr int PK = 8;                    // independent loads in flight per thread, then the scatter (16 measured the same:
+                                             // the pack is not what the small layers wait for)
+    for (int e0 = threadIdx.x; e0 < total; e0 += PK * CONV_THREADS) {
+      float v[PK];
+      int rr[PK], cc[PK];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {          // 8 independent loads in flight, then the scatter
+      for (int u = 0; u < PK; ++u) {
         const int e = e0 + u * CONV_THREADS;
         const int r = e / gcols, c = e - r * gcols;
         rr[u] = r; cc[u] = c;
         v[u] = e < total ? w[tr ? (size_t)r * cols + 16 * ob0 + c : ((size_t)16 * ob0 + r) * cols + c] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < PK; ++u) {
         const int e = e0 + u * CONV_THREADS;
         if (e < total) {
           const int co = 16 * ob0 + (tr ? cc[u] : rr[u]), ci = tr ? rr[u] : cc[u];
@@ -111,12 +113,28 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 
   // The wave's work is one stream of (tile, 16-channel block) steps.  A load cursor runs CONV_AHEAD steps ahead of
   // the multiply cursor through a ring of register buffers, so a block has CONV_AHEAD multiply steps (of this wave
   // and of the waves sharing its SIMD) to arrive from HBM -- tile boundaries included.
-  struct Cursor { long long t; int m; const float *xb; int b, px; bool pv; };
+  // x is read through a buffer descriptor (the launcher guarantees < 4 GiB): a lane whose pixel or channel does not exist
+  // asks for an offset beyond the records and gets zeros back, so the loads are UNCONDITIONAL instructions.  (With
+  // conditional global loads every ring slot sat under control flow and the compiler waited for ALL outstanding loads --
+  // s_waitcnt vmcnt(0) -- before each multiply step: the 4-deep ring hid one step of latency instead of four.)
+  // The loads and their waits are inline assembly: hipcc's own wait insertion, even for unconditional buffer loads in this
+  // loop, waits at every step until the step's OWN four loads are the newest outstanding ones (s_waitcnt vmcnt(3..0)), i.e.
+  // until the three younger ring slots have arrived as well -- a prefetch distance of one step instead of four (profile:
+  // the 128-channel layers ran at 2.0x their MFMA bound).  Here a step waits for `vmcnt(4 * (CONV_AHEAD - 1))`: loads return
+  // in order, every step issues exactly four (out-of-range lanes included), so at most the 12 younger loads may still be
+  // in flight when ring[u] is read; stores and the compiler's own loads only make that wait more conservative.
+  typedef int cv_i32x4 __attribute__((ext_vector_type(4)));
+  typedef float cv_f32x2 __attribute__((ext_vector_type(2)));
+  const unsigned long long xaddr = reinterpret_cast<unsigned long long>(x);
+  const cv_i32x4 xr = {__builtin_amdgcn_readfirstlane((int)(unsigned)xaddr),
+                       __builtin_amdgcn_readfirstlane((int)(unsigned)((xaddr >> 32) & 0xFFFFull)),   // stride 0
+                       __builtin_amdgcn_readfirstlane((int)x_bytes), 0x00020000};
+  struct Cursor { long long t; int m; unsigned xoff; int b, px; bool pv; };
   auto locate = [&](Cursor &c) {
     const int b = (int)(c.t / tpb);
     const int px = ((int)(c.t - (long long)b * tpb) << 5) + 2 * j;
     c.pv = c.t < tiles && px < P;
-    c.xb = x + (long long)b * Cin * P + px;
+    c.xoff = (unsigned)(((long long)b * Cin * P + px) * 4);       // byte offset of (b, channel 0, px); meaningful when pv
     c.b = b;
     c.px = px;
   };
@@ -127,15 +145,18 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 
       locate(c);
     }
   };
-  float2 ring[CONV_AHEAD][4];
-  auto load = [&](const Cursor &c, float2(&d)[4]) {
+  cv_f32x2 ring[CONV_AHEAD][4];
+  auto load = [&](const Cursor &c, cv_f32x2(&d)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int ch = 16 * c.m + 4 * s + g;
-      d[s] = (c.pv && ch < Cin) ? *reinterpret_cast<const float2 *>(c.xb + (long long)ch * P) : make_float2(0.f, 0.f);
+      // (arithmetic, not `ok ? offset : out_of_range`: the compiler turns that select back into a branch around the load)
+      const unsigned oob = (unsigned)(-(int)!(c.pv && ch < Cin)) & 0xFFFFFFF0u;
+      const unsigned off = (c.xoff + (unsigned)ch * (unsigned)P * 4u) | oob;
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(d[s]) : "v"(off), "s"(xr));
     }
   };
-  Cursor lc{t0, 0, nullptr, 0, 0, false}, mc{t0, 0, nullptr, 0, 0, false};
+  Cursor lc{t0, 0, 0u, 0, 0, false}, mc{t0, 0, 0u, 0, 0, false};
   locate(lc);
   locate(mc);
 #pragma unroll
@@ -177,9 +198,13 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 
   // it pushed the ring buffer out of registers)
   for (bool more = true; more;) {
     more = mc.t < tiles;
+    // past the last tile: the ring's final (unused, out-of-range) loads must land before their registers are reused
+    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int u = 0; u < CONV_AHEAD; ++u) {
       if (mc.t < tiles) {                    // wave-uniform
+        static_assert(CONV_AHEAD == 4, "the wait below counts 4 * (CONV_AHEAD - 1) younger loads");
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(ring[u][0]), "+v"(ring[u][1]), "+v"(ring[u][2]), "+v"(ring[u][3]));
         if (in_mean != nullptr) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
@@ -242,6 +267,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 
     }
     if (STATS && (st_tiles >= CONV_STAT_TILES || !more)) st_flush();     // at most CONV_AHEAD - 1 tiles over the limit
   }
+
   if (STATS) {
     __syncthreads();
     const double *slots = reinterpret_cast<const double *>(conv_in + nbi * 16);
@@ -565,12 +591,15 @@ static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, cons
   const long long gx = cg.gx;
   PWCLO_REQUIRE((in_mean == nullptr) == (in_invstd == nullptr), "conv1x1_forward: in_mean and in_invstd must be given together%s", "");
   PWCLO_REQUIRE(lds <= 154 * 1024, "conv1x1_forward: cin=%d cout=%d need %zu bytes of LDS for the weights", cin, cout, lds);
+  PWCLO_REQUIRE((long long)b * cin * p * 4 < (1ll << 32) - 16, "conv1x1_forward: input of %lld bytes: the kernel addresses x with "
+                "32-bit byte offsets (< 4 GiB)", (long long)b * cin * p * 4);
+  const unsigned x_bytes = (unsigned)((long long)b * cin * p * 4);
   hipStream_t st = current_stream();
   dim3 grid((unsigned)gx, (unsigned)gy), block(CONV_THREADS);
 #define PWCLO_CONV_LAUNCH_S(N, S)                                                                                \
     PWCLO_REQUIRE(allow_lds(conv1x1_kernel<N, S>, lds), "conv1x1_forward: cannot reserve %zu bytes of LDS", lds); \
     hipLaunchKernelGGL((conv1x1_kernel<N, S>), grid, block, lds, st, b, cin, cout, p, nbi, ld_o, ld_i, x, w, y,   \
-                       scale, shift, relu, pool, in_mean, in_invstd, in_gamma, in_beta, stats);
+                       scale, shift, relu, pool, in_mean, in_invstd, in_gamma, in_beta, stats, x_bytes);
 #define PWCLO_CONV_LAUNCH(N)                                                                                     \
   case N:                                                                                                        \
     if (stats != nullptr) { PWCLO_CONV_LAUNCH_S(N, true) } else { PWCLO_CONV_LAUNCH_S(N, false) }                \
