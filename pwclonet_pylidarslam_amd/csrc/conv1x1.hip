@@ -39,8 +39,10 @@ constexpr int WGRAD_MAXV = 8;                // float4 per thread of one staged 
 // relu) needs no statistics pass over y.  Per lane the two pixels of a tile are added in fp32 for at most CONV_STAT_TILES
 // tiles (64 values), then reduced over the 16 lanes of a row (DPP) and added to the wave's own fp64 slot in LDS by one
 // lane; the 8 slots are summed in wave order at the end: deterministic, and within ~1e-6 of the fp64 pass it replaces.
-template <int NBO, bool STATS>
-__global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 1 : 2)) void conv1x1_kernel(int B, int Cin, int Cout, int P, int nbi,
+// LEAN: no folded BatchNorm, no pooling in the epilogue and y below 4 GiB (training forward / input gradient): the short
+// epilogue with descriptor stores; STATS implies LEAN.
+template <int NBO, bool STATS, bool LEAN>
+__global__ __launch_bounds__(CONV_THREADS, (NBO <= 2 || (NBO == 3 && !STATS) ? 4 : (STATS && NBO > 4) ? 1 : 2)) void conv1x1_kernel(int B, int Cin, int Cout, int P, int nbi,
                                                               long long w_ld_o, long long w_ld_i,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y,
@@ -50,7 +52,8 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 
                                                               const float *__restrict__ in_invstd,
                                                               const float *__restrict__ in_gamma,
                                                               const float *__restrict__ in_beta,
-                                                              double *__restrict__ stats_partial, unsigned x_bytes) {
+                                                              double *__restrict__ stats_partial, unsigned x_bytes,
+                                                              unsigned y_bytes) {
   extern __shared__ float4 conv_w[];         // [NBO][nbi][64 lanes] : the 4 k-steps of one (o, m) tile per lane
   const int ob0 = blockIdx.y * NBO;
   {
@@ -129,6 +132,9 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 
   const cv_i32x4 xr = {__builtin_amdgcn_readfirstlane((int)(unsigned)xaddr),
                        __builtin_amdgcn_readfirstlane((int)(unsigned)((xaddr >> 32) & 0xFFFFull)),   // stride 0
                        __builtin_amdgcn_readfirstlane((int)x_bytes), 0x00020000};
+  static_assert(LEAN || !STATS, "the statistics epilogue is part of the short one");
+  constexpr bool lean = LEAN;
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)y_bytes, 0x00020000);
   struct Cursor { long long t; int m; unsigned xoff; int b, px; bool pv; };
   auto locate = [&](Cursor &c) {
     const int b = (int)(c.t / tpb);
@@ -226,7 +232,34 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 3 ? 4 : (STATS && NBO > 4) ? 
         load(lc, ring[u]);                   // the slot just consumed takes the step CONV_AHEAD ahead
         advance(lc);
         if (mc.m == nbi - 1) {
-          if (mc.pv) {
+          if (lean) {
+            // Training forward / input gradient (no folded BatchNorm, no pooling): y through its descriptor.  The lane's
+            // part of the address (cloud, pixel pair, row 4 g of the block) is ONE 32-bit offset per tile; the (block, row)
+            // part is wave-uniform and travels as the store's scalar offset -- 2 moves + 1 store per row instead of the
+            // ~37 vector instructions (64-bit address, guards, selects) of the general epilogue below, which was a third
+            // of this kernel's vector-pipe time at 128 channels (the fp32 MFMA does not share the pipe).
+            if (mc.pv) {
+              const unsigned yoff = (unsigned)((((long long)mc.b * Cout + 16 * ob0 + 4 * g) * P + mc.px) * 4);
+              const int row_bytes = P * 4;
+#pragma unroll
+              for (int o = 0; o < NBO; ++o) {
+                const bool whole = 16 * (ob0 + o) + 16 <= Cout;            // wave-uniform: only the last block has a tail
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const float v0 = acc[o][0][r], v1 = acc[o][1][r];
+                  if (STATS) {                // padding channels hold exact zeros: they add nothing and are never read
+                    st_s[o][r] += v0 + v1;
+                    st_q[o][r] = fmaf(v1, v1, fmaf(v0, v0, st_q[o][r]));
+                  }
+                  if (whole || 16 * (ob0 + o) + 4 * g + r < Cout) {
+                    typedef unsigned cv_u32x2 __attribute__((ext_vector_type(2)));
+                    const cv_u32x2 bits = {__float_as_uint(v0), __float_as_uint(v1)};
+                    __builtin_amdgcn_raw_buffer_store_b64(bits, yr, (int)yoff, (16 * o + r) * row_bytes, 0);
+                  }
+                }
+              }
+            }
+          } else if (mc.pv) {
             // ep_pool = K > 0: the row of K consecutive pixels (K / 2 neighbouring lanes, rows never straddle a 32-pixel
             // tile) is reduced to its maximum and only that is written: y is (B, Cout, P / K)
             float *yb = ep_pool > 0 ? y + ((long long)mc.b * Cout * (P / ep_pool) + mc.px / ep_pool)
@@ -544,7 +577,7 @@ using namespace pwclo;
 
 // Launch shape of the forward / input-gradient kernel: gy groups of nbo output blocks, gx persistent tile workers.
 struct ConvGrid { int nbi, nbo, gy; long long gx; size_t lds; };
-static ConvGrid conv_grid(int b, int cin, int cout, int p, bool stats) {
+static ConvGrid conv_grid(int b, int cin, int cout, int p, bool stats, bool lean = false) {
   ConvGrid cg;
   cg.nbi = ceil_div(cin, 16);
   const int nbo_all = ceil_div(cout, 16);
@@ -566,7 +599,9 @@ static ConvGrid conv_grid(int b, int cin, int cout, int p, bool stats) {
   cg.lds = (size_t)cg.nbo * cg.nbi * WAVE * sizeof(float4) + (size_t)cg.nbi * 16 * sizeof(float4);   // weights + input transform
   if (stats) cg.lds += (size_t)CONV_WAVES * cg.nbo * 16 * 2 * sizeof(double);                        // + the waves' fp64 slots
   const long long tiles = (long long)b * ceil_div(p, 32);
-  const int per_cu = (cg.lds <= 72 * 1024 && cg.nbo <= 3) ? 2 : 1;      // workgroups a CU can hold (LDS, registers)
+  // workgroups a CU can hold (LDS, registers): the short-epilogue kernels without statistics stay under 128 VGPRs at every
+  // width (4 waves per SIMD), the others from 4 output blocks on do not
+  const int per_cu = (cg.lds <= 72 * 1024 && (cg.nbo <= 3 || (lean && !stats))) ? 2 : 1;
   cg.gx = (long long)conv_grid_x() * per_cu / cg.gy;
   const long long need = (tiles + CONV_WAVES - 1) / CONV_WAVES;
   if (cg.gx > need) cg.gx = need;
@@ -585,7 +620,13 @@ static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, cons
                 "conv1x1_forward: pooled rows of k=%d pixels need k in {4,8,16,32} dividing p=%d", pool, p);
   // transposed = 1: w is stored (cin, cout) row-major -- the input-gradient pass of a layer whose weight it is.
   const long long ld_o = transposed ? 1 : cin, ld_i = transposed ? cout : 1;
-  const ConvGrid cg = conv_grid(b, cin, cout, p, stats != nullptr);
+  // y through 32-bit offsets where it fits (0: the general epilogue with 64-bit addresses)
+  const long long yb64 = (long long)b * cout * p * 4;
+  const unsigned y_bytes = (pool == 0 && yb64 < (1ll << 32) - 16) ? (unsigned)yb64 : 0u;
+  const bool lean = scale == nullptr && pool == 0 && y_bytes != 0u;
+  PWCLO_REQUIRE(stats == nullptr || lean, "conv1x1_forward_bnstats: output of %lld bytes (the statistics epilogue addresses y with "
+                "32-bit byte offsets)", yb64);
+  const ConvGrid cg = conv_grid(b, cin, cout, p, stats != nullptr, lean);
   const int nbi = cg.nbi, nbo = cg.nbo, gy = cg.gy;
   const size_t lds = cg.lds;
   const long long gx = cg.gx;
@@ -596,13 +637,15 @@ static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, cons
   const unsigned x_bytes = (unsigned)((long long)b * cin * p * 4);
   hipStream_t st = current_stream();
   dim3 grid((unsigned)gx, (unsigned)gy), block(CONV_THREADS);
-#define PWCLO_CONV_LAUNCH_S(N, S)                                                                                \
-    PWCLO_REQUIRE(allow_lds(conv1x1_kernel<N, S>, lds), "conv1x1_forward: cannot reserve %zu bytes of LDS", lds); \
-    hipLaunchKernelGGL((conv1x1_kernel<N, S>), grid, block, lds, st, b, cin, cout, p, nbi, ld_o, ld_i, x, w, y,   \
-                       scale, shift, relu, pool, in_mean, in_invstd, in_gamma, in_beta, stats, x_bytes);
+#define PWCLO_CONV_LAUNCH_S(N, S, L)                                                                             \
+    PWCLO_REQUIRE(allow_lds(conv1x1_kernel<N, S, L>, lds), "conv1x1_forward: cannot reserve %zu bytes of LDS", lds); \
+    hipLaunchKernelGGL((conv1x1_kernel<N, S, L>), grid, block, lds, st, b, cin, cout, p, nbi, ld_o, ld_i, x, w, y, \
+                       scale, shift, relu, pool, in_mean, in_invstd, in_gamma, in_beta, stats, x_bytes, y_bytes);
 #define PWCLO_CONV_LAUNCH(N)                                                                                     \
   case N:                                                                                                        \
-    if (stats != nullptr) { PWCLO_CONV_LAUNCH_S(N, true) } else { PWCLO_CONV_LAUNCH_S(N, false) }                \
+    if (stats != nullptr) { PWCLO_CONV_LAUNCH_S(N, true, true) }                                                 \
+    else if (lean) { PWCLO_CONV_LAUNCH_S(N, false, true) }                                                       \
+    else { PWCLO_CONV_LAUNCH_S(N, false, false) }                                                                \
     break
   switch (nbo) {
     PWCLO_CONV_LAUNCH(1);
