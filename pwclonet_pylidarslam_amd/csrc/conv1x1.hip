@@ -106,7 +106,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 2 || (NBO == 3 && !STATS) ? 4
     __syncthreads();
   }
   const float4 *conv_in = conv_w + NBO * nbi * WAVE;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably uniform
   const int g = lane >> 4, j = lane & 15;
   const int tpb = (P + 31) >> 5;             // 32-pixel tiles per batch element: lane (g, j) owns pixels 2j, 2j + 1
   const long long tiles = (long long)B * tpb;
@@ -135,34 +135,47 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 2 || (NBO == 3 && !STATS) ? 4
   static_assert(LEAN || !STATS, "the statistics epilogue is part of the short one");
   constexpr bool lean = LEAN;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)y_bytes, 0x00020000);
-  struct Cursor { long long t; int m; unsigned xoff; int b, px; bool pv; };
+  // Cursor arithmetic is scalar: the tile number, its cloud b and its position r inside the cloud are wave-uniform (the wave
+  // index above comes through readfirstlane), and moving to the wave's next tile adds the precomputed quotient / remainder
+  // of the stride instead of dividing again (a 64-bit division per tile on the VECTOR pipe, twice, in the first version).
+  // Per lane a tile costs one offset: xoff = byte offset of (b, channel g, pixel pair), or out of range.
+  const int qstep = (int)(tstep / tpb), rstep = (int)(tstep - (long long)qstep * tpb);
+  const int row_bytes_x = P * 4;
+  struct Cursor { long long t; int m, b, r; unsigned xoff; int px; bool pv; };
   auto locate = [&](Cursor &c) {
-    const int b = (int)(c.t / tpb);
-    const int px = ((int)(c.t - (long long)b * tpb) << 5) + 2 * j;
+    const int px = (c.r << 5) + 2 * j;
     c.pv = c.t < tiles && px < P;
-    c.xoff = (unsigned)(((long long)b * Cin * P + px) * 4);       // byte offset of (b, channel 0, px); meaningful when pv
-    c.b = b;
+    c.xoff = c.pv ? (unsigned)((((long long)c.b * Cin + g) * P + px) * 4) : 0xFFFFFFF0u;
     c.px = px;
   };
   auto advance = [&](Cursor &c) {
     if (++c.m == nbi) {
       c.m = 0;
       c.t += tstep;
+      c.b += qstep;
+      c.r += rstep;
+      if (c.r >= tpb) { c.r -= tpb; ++c.b; }
       locate(c);
     }
   };
+  // channel tail (Cin not a multiple of 16): in the LAST 16-channel block the lanes of row group g read channel
+  // 16 (nbi - 1) + 4 s + g; those beyond Cin ask out of range
+  unsigned tail[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) tail[s4] = (16 * (nbi - 1) + 4 * s4 + g < Cin) ? 0u : 0xFFFFFFF0u;
   cv_f32x2 ring[CONV_AHEAD][4];
   auto load = [&](const Cursor &c, cv_f32x2(&d)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int ch = 16 * c.m + 4 * s + g;
-      // (arithmetic, not `ok ? offset : out_of_range`: the compiler turns that select back into a branch around the load)
-      const unsigned oob = (unsigned)(-(int)!(c.pv && ch < Cin)) & 0xFFFFFFF0u;
-      const unsigned off = (c.xoff + (unsigned)ch * (unsigned)P * 4u) | oob;
-      asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(d[s]) : "v"(off), "s"(xr));
+      // lane part in the vector offset (| the tail mask in the last block), the block / row part (16 m + 4 s) rows as the
+      // scalar offset: one vector instruction per load
+      const unsigned off = c.xoff | (c.m == nbi - 1 ? tail[s] : 0u);
+      const int soff = (16 * c.m + 4 * s) * row_bytes_x;
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(d[s]) : "v"(off), "s"(xr), "s"(soff));
     }
   };
-  Cursor lc{t0, 0, 0u, 0, 0, false}, mc{t0, 0, 0u, 0, 0, false};
+  const int b0 = (int)(t0 / tpb), r0 = (int)(t0 - (long long)b0 * tpb);
+  Cursor lc{t0, 0, b0, r0, 0u, 0, false}, mc{t0, 0, b0, r0, 0u, 0, false};
   locate(lc);
   locate(mc);
 #pragma unroll
@@ -211,6 +224,11 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 2 || (NBO == 3 && !STATS) ? 4
       if (mc.t < tiles) {                    // wave-uniform
         static_assert(CONV_AHEAD == 4, "the wait below counts 4 * (CONV_AHEAD - 1) younger loads");
         asm volatile("s_waitcnt vmcnt(12)" : "+v"(ring[u][0]), "+v"(ring[u][1]), "+v"(ring[u][2]), "+v"(ring[u][3]));
+        if (mc.m == nbi - 1 && (Cin & 15) != 0) {      // wave-uniform.  Channel tail: exact zeros whatever the descriptor's
+#pragma unroll                                        // range check makes of vector + scalar offset (0 x NaN would be NaN)
+          for (int s = 0; s < 4; ++s)
+            if (tail[s] != 0u) ring[u][s] = cv_f32x2{0.f, 0.f};
+        }
         if (in_mean != nullptr) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
@@ -600,8 +618,8 @@ static ConvGrid conv_grid(int b, int cin, int cout, int p, bool stats, bool lean
   if (stats) cg.lds += (size_t)CONV_WAVES * cg.nbo * 16 * 2 * sizeof(double);                        // + the waves' fp64 slots
   const long long tiles = (long long)b * ceil_div(p, 32);
   // workgroups a CU can hold (LDS, registers): the short-epilogue kernels without statistics stay under 128 VGPRs at every
-  // width (4 waves per SIMD), the others from 4 output blocks on do not
-  const int per_cu = (cg.lds <= 72 * 1024 && (cg.nbo <= 3 || (lean && !stats))) ? 2 : 1;
+  // width (4 waves per SIMD), with statistics up to 4 output blocks, the general epilogue up to 3
+  const int per_cu = (cg.lds <= 72 * 1024 && (cg.nbo <= 3 || (lean && !stats) || (stats && cg.nbo <= 4))) ? 2 : 1;
   cg.gx = (long long)conv_grid_x() * per_cu / cg.gy;
   const long long need = (tiles + CONV_WAVES - 1) / CONV_WAVES;
   if (cg.gx > need) cg.gx = need;

@@ -402,6 +402,34 @@ def test_training_stack_without_normalised_activations_matches_torch(cuda, poole
             assert int(p) == 1, n                             # num_batches_tracked (the float64 copy was not advanced)
 
 
+@pytest.mark.parametrize("cin,cout,P", [(19, 16, 64), (67, 128, 36), (3, 5, 4), (138, 128, 1028)])
+def test_conv1x1_channel_tail_does_not_read_the_next_cloud(cuda, cin, cout, P):
+    """The kernel reads its input in 16-channel blocks through a buffer descriptor; the lanes of the last block that
+    stand for channels >= cin would alias the NEXT cloud's first channels.  They must contribute exact zeros: with NaNs in
+    exactly those aliased rows (cloud 1, channels 0 .. 15 - cin % 16) cloud 0's output stays finite and equal to the
+    float64 product, forward and input gradient (whose "channels" are the layer's cout) alike; cloud 1's is NaN."""
+    from pwclonet_pylidarslam_amd import conv1x1
+    gen = torch.Generator().manual_seed(cin * 7 + P)
+    x = torch.randn(2, cin, P, generator=gen)
+    w = torch.randn(cout, cin, generator=gen) / cin ** 0.5
+    alias = 16 - cin % 16 if cin % 16 else 0
+    x[1, :max(alias, 1)] = float("nan")
+    xc, wc = x.to(cuda), w.to(cuda)
+    y = conv1x1._forward(xc, wc, False, cin, cout)
+    want = torch.einsum("oi,ip->op", w.double(), x[0].double())
+    assert torch.isfinite(y[0]).all()
+    assert (y[0].cpu().double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    assert torch.isnan(y[1]).all()
+    dy = torch.randn(2, cout, P, generator=gen)
+    alias_o = 16 - cout % 16 if cout % 16 else 0
+    dy[1, :max(alias_o, 1)] = float("nan")
+    dx = conv1x1._forward(dy.to(cuda), wc, True, cout, cin)
+    want_dx = torch.einsum("oi,op->ip", w.double(), dy[0].double())
+    assert torch.isfinite(dx[0]).all()
+    assert (dx[0].cpu().double() - want_dx).abs().max().item() <= 1e-5 * want_dx.abs().max().item()
+    assert torch.isnan(dx[1]).all()
+
+
 @pytest.mark.parametrize("B,cin,cout,P,shift", [(2, 6, 8, 4096, 0.0), (3, 35, 48, 1028, 0.0), (1, 64, 128, 64, 0.0),
                                                  (2, 138, 128, 512, 0.0), (2, 19, 200, 260, 0.0), (1, 3, 5, 4, 0.0),
                                                  (64, 8, 16, 65536, 3.0), (4, 67, 64, 16384, 5.0)])
