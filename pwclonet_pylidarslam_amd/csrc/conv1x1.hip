@@ -369,50 +369,63 @@ __global__ __launch_bounds__(CONV_THREADS, ((RO * RM <= 2 && !XF) ? 4 : 2)) void
     boff[q] = (wc + wm * q < nbi && rm < Cin) ? (Cout + rm) * ld + 4 * g : -1;
   }
 
+  // Staging plan of this thread, fixed for the whole kernel: element e = threadIdx.x + u * 512 of a chunk is float4 q of
+  // row r (dY rows first, then X rows).  Its source address without the chunk's (cloud, first pixel) part and its place in
+  // the stage are computed ONCE instead of dividing e by the (runtime) row length for every element of every chunk.
+  // (Measured, profiles/r03: -1.5 % only; so was a second chunk of register prefetch behind hand-placed vmcnt waits, which
+  // cost the narrow layers their second workgroup per CU -- the kernel's 0.55 matrix-pipe busy is not a staging problem.)
   float4 pre[WGRAD_MAXV];                   // the next chunk on its way from HBM while this one is multiplied
+  const float *src0[WGRAD_MAXV];            // row start + 4 q of cloud 0 (nullptr: no element)
+  int dst0[WGRAD_MAXV], qpx[WGRAD_MAXV], xrow[WGRAD_MAXV];   // stage offset, first pixel inside the chunk, X channel or -1
+#pragma unroll
+  for (int u = 0; u < WGRAD_MAXV; ++u) {
+    const int e = threadIdx.x + u * CONV_THREADS;
+    const int r = e / vec, q = e - r * vec;
+    const bool any = e < rows * vec;
+    const bool is_dy = r < Cout;
+    src0[u] = !any ? nullptr : is_dy ? dy + (long long)r * P + 4 * q : x + (long long)(r - Cout) * P + 4 * q;
+    dst0[u] = r * ld + 4 * q;
+    qpx[u] = 4 * q;
+    xrow[u] = (any && !is_dy) ? r - Cout : -1;
+  }
+  const long long cloud_dy = (long long)Cout * P, cloud_x = (long long)Cin * P;
   auto fetch = [&](long long c) {
-    const int b = (int)(c / cpb);
+    const int b = (int)(c / cpb);           // (wave-uniform: scalar division)
     const int px0 = (int)(c - (long long)b * cpb) * CP;
+    const long long add_dy = b * cloud_dy + px0, add_x = b * cloud_x + px0;
 #pragma unroll
     for (int u = 0; u < WGRAD_MAXV; ++u) {
-      const int e = threadIdx.x + u * CONV_THREADS;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < rows * vec) {
-        const int r = e / vec, q = e - r * vec;
-        const int px = px0 + 4 * q;
-        if (px < P) {
-          const float *src = (r < Cout) ? dy + ((long long)b * Cout + r) * P : x + ((long long)b * Cin + (r - Cout)) * P;
-          v = *reinterpret_cast<const float4 *>(src + px);
-        }
-      }
+      if (src0[u] != nullptr && px0 + qpx[u] < P)
+        v = *reinterpret_cast<const float4 *>(src0[u] + (xrow[u] < 0 ? add_dy : add_x));
       pre[u] = v;
     }
   };
   // XF: per-input-channel (mean, invstd, gamma, beta) of the previous layer's BatchNorm, in LDS behind the two stages;
   // X = max(bn(x), 0) is applied when a fetched chunk is written to its stage (pixels beyond the row stay 0)
-  float4 *xf = reinterpret_cast<float4 *>(conv_s + (size_t)2 * rows * ld);
+  float *zero_row = conv_s + (size_t)2 * rows * ld;                        // 16 zeros: operand of padding rows / tiles
+  float4 *xf = reinterpret_cast<float4 *>(zero_row + 16);
+  if (threadIdx.x < 16) zero_row[threadIdx.x] = 0.f;
   if (XF) {
     for (int ci = threadIdx.x; ci < Cin; ci += CONV_THREADS)
       xf[ci] = make_float4(in_mean[ci], in_invstd[ci], in_gamma ? in_gamma[ci] : 1.f, in_beta ? in_beta[ci] : 0.f);
-    __syncthreads();
   }
+  __syncthreads();
   auto put = [&](int buf, long long c) {
     float *dst = conv_s + (size_t)buf * rows * ld;
     const int px0 = (int)(c - (c / cpb) * cpb) * CP;
 #pragma unroll
     for (int u = 0; u < WGRAD_MAXV; ++u) {
-      const int e = threadIdx.x + u * CONV_THREADS;
-      if (e < rows * vec) {
-        const int r = e / vec, q = e - r * vec;
+      if (src0[u] != nullptr) {
         float4 v = pre[u];
-        if (XF && r >= Cout && px0 + 4 * q < P) {
-          const float4 t = xf[r - Cout];
+        if (XF && xrow[u] >= 0 && px0 + qpx[u] < P) {
+          const float4 t = xf[xrow[u]];
           v.x = relu_nan(((v.x - t.x) * t.y) * t.z + t.w);
           v.y = relu_nan(((v.y - t.x) * t.y) * t.z + t.w);
           v.z = relu_nan(((v.z - t.x) * t.y) * t.z + t.w);
           v.w = relu_nan(((v.w - t.x) * t.y) * t.z + t.w);
         }
-        *reinterpret_cast<float4 *>(dst + (size_t)r * ld + 4 * q) = v;
+        *reinterpret_cast<float4 *>(dst + dst0[u]) = v;
       }
     }
   };
@@ -428,15 +441,22 @@ __global__ __launch_bounds__(CONV_THREADS, ((RO * RM <= 2 && !XF) ? 4 : 2)) void
     const long long cn = c + gridDim.x;
     if (cn < chunks) fetch(cn);
     const float *sd = conv_s + (size_t)buf * rows * ld;
-    for (int sc = phase; sc < (CP >> 4); sc += ph) {
+    // operand reads are unconditional (a padding row / absent tile reads the zero row) and one sub-chunk ahead of the
+    // multiplies: the 16-pixel step used to start with its reads and an s_waitcnt lgkmcnt(0)
+    float4 av[RO], bv[RM];
+    auto read_ops = [&](int sc, float4(&a)[RO], float4(&bb)[RM]) {
       const float *sp = sd + 16 * sc;
-      float4 av[RO], bv[RM];
 #pragma unroll
-      for (int r = 0; r < RO; ++r)
-        av[r] = aoff[r] >= 0 ? *reinterpret_cast<const float4 *>(sp + aoff[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < RO; ++r) a[r] = *reinterpret_cast<const float4 *>(aoff[r] >= 0 ? sp + aoff[r] : zero_row + 4 * g);
 #pragma unroll
-      for (int q = 0; q < RM; ++q)
-        bv[q] = boff[q] >= 0 ? *reinterpret_cast<const float4 *>(sp + boff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < RM; ++q) bb[q] = *reinterpret_cast<const float4 *>(boff[q] >= 0 ? sp + boff[q] : zero_row + 4 * g);
+    };
+    const int nsc = CP >> 4;
+    if (phase < nsc) read_ops(phase, av, bv);
+    for (int sc = phase; sc < nsc; sc += ph) {
+      float4 an[RO], bn[RM];
+      const int scn = sc + ph < nsc ? sc + ph : sc;          // (the last step re-reads its own operands: no branch)
+      read_ops(scn, an, bn);
 #pragma unroll
       for (int r = 0; r < RO; ++r)
 #pragma unroll
@@ -446,6 +466,10 @@ __global__ __launch_bounds__(CONV_THREADS, ((RO * RM <= 2 && !XF) ? 4 : 2)) void
           acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].z, bv[q].z, acc[r][q], 0, 0, 0);
           acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].w, bv[q].w, acc[r][q], 0, 0, 0);
         }
+#pragma unroll
+      for (int r = 0; r < RO; ++r) av[r] = an[r];
+#pragma unroll
+      for (int q = 0; q < RM; ++q) bv[q] = bn[q];
     }
     if (cn < chunks) put(buf ^ 1, cn);      // the other buffer was last read before the previous barrier
     __syncthreads();
@@ -749,7 +773,7 @@ static void conv1x1_wgrad_launch(int b, int cin, int cout, int p, const float *d
   hipStream_t st = current_stream();
   float *partial = reinterpret_cast<float *>(workspace);
   PWCLO_REQUIRE(pl.ro > 0, "conv1x1_wgrad: cin=%d cout=%d: more than 4 x 4 tiles of 16 x 16 per wave", cin, cout);
-  const size_t xf_lds = in_mean != nullptr ? (size_t)cin * sizeof(float4) : 0;   // the input transform's parameters
+  const size_t xf_lds = 64 + (in_mean != nullptr ? (size_t)cin * sizeof(float4) : 0);   // the zero row + the input transform's parameters
 #define PWCLO_WGRAD_LAUNCH_X(R, M, X)                                                                                  \
   {                                                                                                                    \
     PWCLO_REQUIRE(allow_lds(conv1x1_wgrad_kernel<R, M, X>, pl.lds + xf_lds), "conv1x1_wgrad: cannot reserve %zu bytes of LDS",  \
