@@ -45,6 +45,8 @@ def supported_layer(conv, batch, pixels, ndim):
     cin, cout, P = conv.in_channels, conv.out_channels, pixels
     if P % 4 != 0 or cin > 512 or cout > 512 or batch * (-(-P // 64)) >= 2 ** 31:
         return False
+    if 4 * batch * max(cin, cout) * P >= 2 ** 32 - 16:        # the kernels address x (forward) / dy (input gradient) with
+        return False                                          # 32-bit byte offsets through a buffer descriptor
     # weight gradient: double-buffered 32-pixel chunks of all cin + cout rows in LDS, 7 float4 of staging per thread
     return (_fits(cin, cout) and _fits(cout, cin) and 2 * (cin + cout) * 36 * 4 <= 150 * 1024
             and (cin + cout) * 8 <= 7 * 512 and _wgrad_split(cin, cout))

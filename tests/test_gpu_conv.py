@@ -357,6 +357,10 @@ def test_conv1x1_supported_matches_what_the_launchers_accept(cuda):
     assert accepted >= 6
     big = torch.nn.Conv2d(600, 64, 1, bias=False).to(cuda)
     assert not conv1x1.supported(torch.randn(1, 600, 4, 4, device=cuda), big)
+    # 32-bit byte offsets into x / dy: 4 GiB and beyond stays on torch (shape check only: no such tensor is allocated here)
+    wide = torch.nn.Conv2d(16, 16, 1, bias=False)
+    assert conv1x1.supported_layer(wide, 64, 65536 * 16 - 64, 4)
+    assert not conv1x1.supported_layer(wide, 64, 65536 * 16, 4)
 
 
 @pytest.mark.parametrize("pooled,K", [(True, 16), (False, 8), (True, 32), (False, 4)])
