@@ -452,6 +452,18 @@ void conv1x1_forward_bnstats_kernel_wrapper(int b, int cin, int cout, int p, con
                                             const float *in_beta, float *y, float eps, float momentum,
                                             float *running_mean, float *running_var, float *save_mean,
                                             float *save_invstd, void *workspace);
+/* Training mode, input gradient through conv <- ReLU <- BatchNorm: da (b, cin, p) = W^T dy -- the gradient w.r.t. the
+ * rectified, normalised input of the convolution -- AND dgamma / dbeta (cin) of the BatchNorm in front of it, summed in the
+ * convolution's epilogue from da and bn_x (b, cin, p), the BatchNorm's input: the reduction pass of
+ * batchnorm_train_backward_kernel_wrapper(relu = 1) without reading da again.  w (cout, cin), dy (b, cout, p); mean /
+ * invstd (cin) the saved statistics, gamma / beta nullable.  Finish with batchnorm_train_backward_apply_kernel_wrapper
+ * (the same dx).  workspace: conv1x1_stats_workspace_bytes(b, cout, cin, p). */
+void conv1x1_dgrad_bnstats_kernel_wrapper(int b, int cin, int cout, int p, const float *dy, const float *w,
+                                          const float *bn_x, const float *mean, const float *invstd, const float *gamma,
+                                          const float *beta, float *da, float *dgamma, float *dbeta, void *workspace);
+void batchnorm_train_backward_apply_kernel_wrapper(int b, int c, int l, const float *x, const float *dy, const float *gamma,
+                                                   const float *beta, const float *save_mean, const float *save_invstd,
+                                                   const float *dgamma, const float *dbeta, float *dx, int relu);
 /* The apply passes of batchnorm_train_forward / batchnorm_train_relu_maxk_forward alone, for statistics obtained that
  * way: y = [relu]((x - mean) * invstd * gamma + beta); pooled / arg / xsel as documented above. */
 void batchnorm_train_apply_kernel_wrapper(int b, int c, int l, const float *x, const float *gamma, const float *beta,

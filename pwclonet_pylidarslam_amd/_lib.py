@@ -78,6 +78,8 @@ SIGNATURES = {
     "conv1x1_bnrelu_wgrad_kernel_wrapper": ([_i, _i, _i, _i] + [_F] * 8, None),
     "conv1x1_wgrad_workspace_bytes": ([_i, _i, _i, _i], ctypes.c_longlong),
     "conv1x1_stats_workspace_bytes": ([_i, _i, _i, _i], ctypes.c_longlong),
+    "conv1x1_dgrad_bnstats_kernel_wrapper": ([_i, _i, _i, _i] + [_F] * 11, None),
+    "batchnorm_train_backward_apply_kernel_wrapper": ([_i, _i, _i] + [_F] * 9 + [_i], None),
     "conv1x1_forward_bnstats_kernel_wrapper": ([_i, _i, _i, _i] + [_F] * 7 + [ctypes.c_float, ctypes.c_float] + [_F] * 5, None),
     "batchnorm_train_apply_kernel_wrapper": ([_i, _i, _i] + [_F] * 6 + [_i], None),
     "batchnorm_train_relu_maxk_apply_kernel_wrapper": ([_i, _i, _i, _i] + [_F] * 8, None),

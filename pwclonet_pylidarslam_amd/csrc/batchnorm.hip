@@ -303,6 +303,12 @@ void bn_forward_finish_launch(int c, int nsplit, long long M, float eps, float m
   check_launch("bn_forward_finish");
 }
 
+void bn_backward_finish_launch(int c, int nsplit, const double *partial, float *dgamma, float *dbeta) {
+  hipLaunchKernelGGL(bn_backward_finish_kernel, dim3(ceil_div(c, 4)), dim3(256), 0, current_stream(), c, nsplit, partial, dgamma,
+                     dbeta);
+  check_launch("bn_backward_finish");
+}
+
 }  // namespace pwclo
 
 using namespace pwclo;
@@ -402,6 +408,27 @@ extern "C" void batchnorm_train_apply_kernel_wrapper(int b, int c, int l, const 
   else
     bn_launch_apply<0, false>(vec, b, c, l, 0.f, x, none, gamma, beta, mean, invstd, none, none, y, st);
   check_launch("batchnorm_train_apply");
+}
+
+// dx = gamma * invstd * (g - dbeta / M - xhat * dgamma / M) with GIVEN dgamma / dbeta (conv1x1_dgrad_bnstats left them): the
+// apply pass of batchnorm_train_backward_kernel_wrapper alone.
+extern "C" void batchnorm_train_backward_apply_kernel_wrapper(int b, int c, int l, const float *x, const float *dy,
+                                                              const float *gamma, const float *beta, const float *save_mean,
+                                                              const float *save_invstd, const float *dgamma,
+                                                              const float *dbeta, float *dx, int relu) {
+  if (b <= 0 || c <= 0 || l <= 0) return;
+  PWCLO_REQUIRE(b <= 65535 && c <= 65535, "batchnorm_train_backward_apply: b=%d c=%d exceed the grid limits", b, c);
+  const bool vec = (l % 4 == 0);
+  PWCLO_REQUIRE(!vec || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(dx) & 15) == 0),
+                "batchnorm_train_backward_apply: x, dy and dx must be 16-byte aligned%s", "");
+  const float inv_m = (float)(1.0 / ((double)b * l));
+  hipStream_t st = current_stream();
+  if (relu)
+    bn_launch_apply<1, true>(vec, b, c, l, inv_m, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, dx, st);
+  else
+    bn_launch_apply<1, false>(vec, b, c, l, inv_m, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, dx, st);
+  check_launch("batchnorm_train_backward_apply");
 }
 
 // ---- BatchNorm -> ReLU -> max over K (tail of the grouped stacks) ------------------------------------------------

@@ -41,8 +41,15 @@ constexpr int WGRAD_MAXV = 8;                // float4 per thread of one staged 
 // lane; the 8 slots are summed in wave order at the end: deterministic, and within ~1e-6 of the fp64 pass it replaces.
 // LEAN: no folded BatchNorm, no pooling in the epilogue and y below 4 GiB (training forward / input gradient): the short
 // epilogue with descriptor stores; STATS implies LEAN.
-template <int NBO, bool STATS, bool LEAN>
-__global__ __launch_bounds__(CONV_THREADS, (NBO <= 2 || (NBO == 3 && !STATS) ? 4 : (STATS && NBO > 4) ? 1 : 2)) void conv1x1_kernel(int B, int Cin, int Cout, int P, int nbi,
+// STATS == 2 (input gradient of a layer that follows a training-mode BatchNorm + ReLU): the output is da, the gradient
+// w.r.t. the rectified, normalised activation; the epilogue reads the BatchNorm's INPUT bx at the tile's own positions
+// (same shape as the output), rebuilds xhat and the ReLU mask with the forward's expression and leaves the partial sums
+// (sum g, sum g * xhat), g = masked da, in the same workspace layout -- the reduction pass of the BatchNorm backward
+// (bn_partial_kernel<1, true>, the largest kernel of the training step: a read of bx AND of da) without reading da again.
+// The per-OUTPUT-channel (mean, invstd, gamma, beta) arrive through the in_* pointers (an input gradient has no input
+// transform).
+template <int NBO, int STATS, bool LEAN>
+__global__ __launch_bounds__(CONV_THREADS, (STATS == 2 ? 2 : NBO <= 2 || (NBO == 3 && !STATS) ? 4 : (STATS && NBO > 4) ? 1 : 2)) void conv1x1_kernel(int B, int Cin, int Cout, int P, int nbi,
                                                               long long w_ld_o, long long w_ld_i,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y,
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 2 || (NBO == 3 && !STATS) ? 4
                                                               const float *__restrict__ in_gamma,
                                                               const float *__restrict__ in_beta,
                                                               double *__restrict__ stats_partial, unsigned x_bytes,
-                                                              unsigned y_bytes) {
+                                                              unsigned y_bytes, const float *__restrict__ bx) {
   extern __shared__ float4 conv_w[];         // [NBO][nbi][64 lanes] : the 4 k-steps of one (o, m) tile per lane
   const int ob0 = blockIdx.y * NBO;
   {
@@ -99,7 +106,14 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 2 || (NBO == 3 && !STATS) ? 4
       double *slots = reinterpret_cast<double *>(conv_in + nbi * 16);       // [8 waves][NBO * 16 channels][2]
       for (int e = threadIdx.x; e < CONV_WAVES * NBO * 16 * 2; e += CONV_THREADS) slots[e] = 0.0;
     }
-    if (in_mean != nullptr)
+    if (STATS == 2) {                        // (mean, invstd, gamma, beta) of this workgroup's OUTPUT channels, behind the slots
+      float4 *outp = reinterpret_cast<float4 *>(reinterpret_cast<double *>(conv_in + nbi * 16) + CONV_WAVES * NBO * 16 * 2);
+      for (int c = threadIdx.x; c < NBO * 16; c += CONV_THREADS) {
+        const int co = 16 * ob0 + c;
+        outp[c] = co < Cout ? make_float4(in_mean[co], in_invstd[co], in_gamma ? in_gamma[co] : 1.f, in_beta ? in_beta[co] : 0.f)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else if (in_mean != nullptr)
       for (int c = threadIdx.x; c < nbi * 16; c += CONV_THREADS)
         conv_in[c] = c < Cin ? make_float4(in_mean[c], in_invstd[c], in_gamma ? in_gamma[c] : 1.f, in_beta ? in_beta[c] : 0.f)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -135,6 +149,10 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 2 || (NBO == 3 && !STATS) ? 4
   static_assert(LEAN || !STATS, "the statistics epilogue is part of the short one");
   constexpr bool lean = LEAN;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bxr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(STATS == 2 ? bx : y), 0,
+                                                                         (int)y_bytes, 0x00020000);
+  const float4 *outp = reinterpret_cast<const float4 *>(
+      reinterpret_cast<const double *>(conv_in + nbi * 16) + CONV_WAVES * NBO * 16 * 2);
   // Cursor arithmetic is scalar: the tile number, its cloud b and its position r inside the cloud are wave-uniform (the wave
   // index above comes through readfirstlane), and moving to the wave's next tile adds the precomputed quotient / remainder
   // of the stride instead of dividing again (a 64-bit division per tile on the VECTOR pipe, twice, in the first version).
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 2 || (NBO == 3 && !STATS) ? 4
           for (int s = 0; s < 4; ++s)
             if (tail[s] != 0u) ring[u][s] = cv_f32x2{0.f, 0.f};
         }
-        if (in_mean != nullptr) {
+        if (STATS != 2 && in_mean != nullptr) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const float4 t = conv_in[16 * mc.m + 4 * s + g];
@@ -259,13 +277,41 @@ __global__ __launch_bounds__(CONV_THREADS, (NBO <= 2 || (NBO == 3 && !STATS) ? 4
             if (mc.pv) {
               const unsigned yoff = (unsigned)((((long long)mc.b * Cout + 16 * ob0 + 4 * g) * P + mc.px) * 4);
               const int row_bytes = P * 4;
+              if (STATS == 2) {
+                // sums of the BatchNorm backward, two output blocks at a time: all their bx loads first, then the arithmetic
+                typedef unsigned cv_u32x2 __attribute__((ext_vector_type(2)));
+                constexpr int HB = NBO < 2 ? NBO : 2;
+#pragma unroll
+                for (int o0 = 0; o0 < NBO; o0 += HB) {
+                  cv_u32x2 xv[HB][4];
+#pragma unroll
+                  for (int oo = 0; oo < HB; ++oo)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                      if (o0 + oo < NBO)       // rows past Cout: in range of the tensor or not, their da is exactly 0
+                        xv[oo][r] = __builtin_amdgcn_raw_buffer_load_b64(bxr, (int)yoff, (16 * (o0 + oo) + r) * row_bytes, 0);
+#pragma unroll
+                  for (int oo = 0; oo < HB; ++oo)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                      if (o0 + oo < NBO) {
+                        const int o = o0 + oo;
+                        const float4 t = outp[o * 16 + 4 * g + r];
+                        const float h0 = (__uint_as_float(xv[oo][r].x) - t.x) * t.y, h1 = (__uint_as_float(xv[oo][r].y) - t.x) * t.y;
+                        const float g0 = (h0 * t.z + t.w > 0.f) ? acc[o][0][r] : 0.f;      // bn_partial_kernel's mask
+                        const float g1 = (h1 * t.z + t.w > 0.f) ? acc[o][1][r] : 0.f;
+                        st_s[o][r] += g0 + g1;
+                        st_q[o][r] = fmaf(g1, h1, fmaf(g0, h0, st_q[o][r]));
+                      }
+                }
+              }
 #pragma unroll
               for (int o = 0; o < NBO; ++o) {
                 const bool whole = 16 * (ob0 + o) + 16 <= Cout;            // wave-uniform: only the last block has a tail
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const float v0 = acc[o][0][r], v1 = acc[o][1][r];
-                  if (STATS) {                // padding channels hold exact zeros: they add nothing and are never read
+                  if (STATS == 1) {           // padding channels hold exact zeros: they add nothing and are never read
                     st_s[o][r] += v0 + v1;
                     st_q[o][r] = fmaf(v1, v1, fmaf(v0, v0, st_q[o][r]));
                   }
@@ -619,7 +665,7 @@ using namespace pwclo;
 
 // Launch shape of the forward / input-gradient kernel: gy groups of nbo output blocks, gx persistent tile workers.
 struct ConvGrid { int nbi, nbo, gy; long long gx; size_t lds; };
-static ConvGrid conv_grid(int b, int cin, int cout, int p, bool stats, bool lean = false) {
+static ConvGrid conv_grid(int b, int cin, int cout, int p, bool stats, bool lean = false, bool bwd_sums = false) {
   ConvGrid cg;
   cg.nbi = ceil_div(cin, 16);
   const int nbo_all = ceil_div(cout, 16);
@@ -640,6 +686,7 @@ static ConvGrid conv_grid(int b, int cin, int cout, int p, bool stats, bool lean
   cg.gy = ceil_div(nbo_all, cg.nbo);
   cg.lds = (size_t)cg.nbo * cg.nbi * WAVE * sizeof(float4) + (size_t)cg.nbi * 16 * sizeof(float4);   // weights + input transform
   if (stats) cg.lds += (size_t)CONV_WAVES * cg.nbo * 16 * 2 * sizeof(double);                        // + the waves' fp64 slots
+  if (bwd_sums) cg.lds += (size_t)cg.nbo * 16 * sizeof(float4);                                      // + the output channels' BatchNorm
   const long long tiles = (long long)b * ceil_div(p, 32);
   // workgroups a CU can hold (LDS, registers): the short-epilogue kernels without statistics stay under 128 VGPRs at every
   // width (4 waves per SIMD), with statistics up to 4 output blocks, the general epilogue up to 3
@@ -654,7 +701,8 @@ static ConvGrid conv_grid(int b, int cin, int cout, int p, bool stats, bool lean
 static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, const float *w, int transposed, float *y,
                            const float *scale, const float *shift, int relu, int pool = 0,
                            const float *in_mean = nullptr, const float *in_invstd = nullptr,
-                           const float *in_gamma = nullptr, const float *in_beta = nullptr, double *stats = nullptr) {
+                           const float *in_gamma = nullptr, const float *in_beta = nullptr, double *stats = nullptr,
+                           const float *bx = nullptr) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0) return;
   if (!conv_args_ok("conv1x1_forward", b, cin, cout, p, x, y, x)) return;
   PWCLO_REQUIRE((scale == nullptr) == (shift == nullptr), "conv1x1_forward: scale and shift must be given together%s", "");
@@ -668,7 +716,7 @@ static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, cons
   const bool lean = scale == nullptr && pool == 0 && y_bytes != 0u;
   PWCLO_REQUIRE(stats == nullptr || lean, "conv1x1_forward_bnstats: output of %lld bytes (the statistics epilogue addresses y with "
                 "32-bit byte offsets)", yb64);
-  const ConvGrid cg = conv_grid(b, cin, cout, p, stats != nullptr, lean);
+  const ConvGrid cg = conv_grid(b, cin, cout, p, stats != nullptr, lean, bx != nullptr);
   const int nbi = cg.nbi, nbo = cg.nbo, gy = cg.gy;
   const size_t lds = cg.lds;
   const long long gx = cg.gx;
@@ -682,12 +730,15 @@ static void conv1x1_launch(int b, int cin, int cout, int p, const float *x, cons
 #define PWCLO_CONV_LAUNCH_S(N, S, L)                                                                             \
     PWCLO_REQUIRE(allow_lds(conv1x1_kernel<N, S, L>, lds), "conv1x1_forward: cannot reserve %zu bytes of LDS", lds); \
     hipLaunchKernelGGL((conv1x1_kernel<N, S, L>), grid, block, lds, st, b, cin, cout, p, nbi, ld_o, ld_i, x, w, y, \
-                       scale, shift, relu, pool, in_mean, in_invstd, in_gamma, in_beta, stats, x_bytes, y_bytes);
+                       scale, shift, relu, pool, in_mean, in_invstd, in_gamma, in_beta, stats, x_bytes, y_bytes, bx);
 #define PWCLO_CONV_LAUNCH(N)                                                                                     \
   case N:                                                                                                        \
-    if (stats != nullptr) { PWCLO_CONV_LAUNCH_S(N, true, true) }                                                 \
-    else if (lean) { PWCLO_CONV_LAUNCH_S(N, false, true) }                                                       \
-    else { PWCLO_CONV_LAUNCH_S(N, false, false) }                                                                \
+    if (stats != nullptr && bx != nullptr) {                                                                     \
+      if (N <= 4) { PWCLO_CONV_LAUNCH_S((N <= 4 ? N : 1), 2, true) }                                             \
+    }                                                                                                            \
+    else if (stats != nullptr) { PWCLO_CONV_LAUNCH_S(N, 1, true) }                                               \
+    else if (lean) { PWCLO_CONV_LAUNCH_S(N, 0, true) }                                                           \
+    else { PWCLO_CONV_LAUNCH_S(N, 0, false) }                                                                    \
     break
   switch (nbo) {
     PWCLO_CONV_LAUNCH(1);
@@ -747,6 +798,32 @@ extern "C" void conv1x1_forward_bnstats_kernel_wrapper(int b, int cin, int cout,
   conv1x1_launch(b, cin, cout, p, x, w, 0, y, nullptr, nullptr, 0, 0, in_mean, in_invstd, in_gamma, in_beta, partial);
   bn_forward_finish_launch(cout, (int)cg.gx, (long long)b * p, eps, momentum, partial, running_mean, running_var, save_mean,
                            save_invstd);
+}
+
+// Input gradient of a layer that follows a training-mode BatchNorm (+ ReLU): da = W^T dy (w stored (cout, cin) like the
+// forward's, dy (b, cout, p)) AND dgamma / dbeta (cin) of that BatchNorm -- sum over (b, p) of g * xhat and of g, g = da where
+// the forward's ReLU let the activation through -- from the convolution's own epilogue; bn_x (b, cin, p) is the BatchNorm's
+// input, mean / invstd its saved statistics, gamma / beta nullable.  What batchnorm_train_backward computes with a pass over
+// bn_x and da; the caller finishes with batchnorm_train_backward_apply.  workspace: conv1x1_stats_workspace_bytes(b, cout, cin, p).
+extern "C" void conv1x1_dgrad_bnstats_kernel_wrapper(int b, int cin, int cout, int p, const float *dy, const float *w,
+                                                     const float *bn_x, const float *mean, const float *invstd,
+                                                     const float *gamma, const float *beta, float *da, float *dgamma,
+                                                     float *dbeta, void *workspace) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0) return;
+  PWCLO_REQUIRE(workspace != nullptr && bn_x != nullptr && mean != nullptr && invstd != nullptr && dgamma != nullptr &&
+                    dbeta != nullptr,
+                "conv1x1_dgrad_bnstats: workspace, bn_x, mean, invstd, dgamma and dbeta are required%s", "");
+  PWCLO_REQUIRE((reinterpret_cast<uintptr_t>(bn_x) & 15) == 0, "conv1x1_dgrad_bnstats: bn_x must be 16-byte aligned%s", "");
+  // the kernel's "input" is dy (cout rows), its "output" da (cin rows): the transposed view of the forward
+  const ConvGrid cg = conv_grid(b, cout, cin, p, true, true, true);
+  // up to 64 BatchNorm channels: beyond that the epilogue's registers (sums + accumulators + the bx rows) do not fit, and those
+  // layers' tensors are small (the reduction pass costs where channels are few and rows are long)
+  PWCLO_REQUIRE(cg.nbo <= 4, "conv1x1_dgrad_bnstats: cin=%d: at most 64 channels per workgroup (the caller keeps the separate "
+                "reduction pass beyond)", cin);
+  PWCLO_REQUIRE(cg.lds <= 154 * 1024, "conv1x1_dgrad_bnstats: cin=%d cout=%d need %zu bytes of LDS", cin, cout, cg.lds);
+  double *partial = reinterpret_cast<double *>(workspace);
+  conv1x1_launch(b, cout, cin, p, dy, w, 1, da, nullptr, nullptr, 0, 0, mean, invstd, gamma, beta, partial, bn_x);
+  bn_backward_finish_launch(cin, (int)cg.gx, partial, dgamma, dbeta);
 }
 
 extern "C" void conv1x1_affine_maxk_forward_kernel_wrapper(int b, int cin, int cout, int s, int k, const float *x,

@@ -406,6 +406,40 @@ def test_training_stack_without_normalised_activations_matches_torch(cuda, poole
             assert int(p) == 1, n                             # num_batches_tracked (the float64 copy was not advanced)
 
 
+@pytest.mark.parametrize("B,cin,cout,P", [(2, 16, 8, 4096), (3, 48, 35, 1028), (2, 64, 128, 512), (1, 5, 3, 4), (2, 35, 64, 260),
+                                          (32, 16, 8, 65536)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_input_gradient_epilogue_leaves_the_batchnorm_backward_sums(cuda, B, cin, cout, P, affine):
+    """conv1x1_dgrad_bnstats + batchnorm_train_backward_apply against the pair they replace (input-gradient convolution,
+    then batchnorm_train_backward with its own reduction pass): da bit-identical, dgamma / dbeta within 1e-5 of their
+    scale (per-lane fp32 partial sums of <= 64 values instead of fp64 throughout), dx within 1e-5 of its scale."""
+    from pwclonet_pylidarslam_amd import _lib, conv1x1
+    from pwclonet_pylidarslam_amd import batchnorm as hb
+    gen = torch.Generator().manual_seed(B * 13 + cin + cout)
+    x = torch.randn(B, cin, P, generator=gen).to(cuda) * 2 + 0.5            # the BatchNorm's input
+    dy = torch.randn(B, cout, P, generator=gen).to(cuda)
+    w = (torch.randn(cout, cin, generator=gen) / cin ** 0.5).to(cuda)
+    mean = x.mean(dim=(0, 2)).contiguous()
+    invstd = (1.0 / torch.sqrt(x.var(dim=(0, 2), unbiased=False) + 1e-5)).contiguous()
+    gamma = (torch.rand(cin, generator=gen) + 0.5).to(cuda) if affine else None
+    beta = (torch.randn(cin, generator=gen) * 0.3).to(cuda) if affine else None
+    p = lambda t: t.data_ptr() if t is not None else 0
+    da_ref = conv1x1._forward(dy, w, True, cout, cin)
+    dx_ref, dg_ref, db_ref = torch.empty_like(x), torch.empty(cin, device=cuda), torch.empty(cin, device=cuda)
+    _lib.call("batchnorm_train_backward_kernel_wrapper", cuda, B, cin, P, p(x), p(da_ref), p(gamma), p(beta), p(mean), p(invstd),
+              p(dx_ref), p(dg_ref), p(db_ref), p(hb._workspace(cin, cuda)), 1)
+    da, dx, dg, db = torch.empty_like(x), torch.empty_like(x), torch.empty(cin, device=cuda), torch.empty(cin, device=cuda)
+    ws = torch.empty((_lib.load().conv1x1_stats_workspace_bytes(B, cout, cin, P) // 8,), dtype=torch.float64, device=cuda)
+    _lib.call("conv1x1_dgrad_bnstats_kernel_wrapper", cuda, B, cin, cout, P, p(dy), p(w), p(x), p(mean), p(invstd), p(gamma),
+              p(beta), p(da), p(dg), p(db), p(ws))
+    _lib.call("batchnorm_train_backward_apply_kernel_wrapper", cuda, B, cin, P, p(x), p(da), p(gamma), p(beta), p(mean), p(invstd),
+              p(dg), p(db), p(dx), 1)
+    assert torch.equal(da, da_ref)
+    for got, ref, what in ((dg, dg_ref, "dgamma"), (db, db_ref, "dbeta"), (dx, dx_ref, "dx")):
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 1e-5 * scale + 1e-30, (what, (got - ref).abs().max().item(), scale)
+
+
 @pytest.mark.parametrize("cin,cout,P", [(19, 16, 64), (67, 128, 36), (3, 5, 4), (138, 128, 1028)])
 def test_conv1x1_channel_tail_does_not_read_the_next_cloud(cuda, cin, cout, P):
     """The kernel reads its input in 16-channel blocks through a buffer descriptor; the lanes of the last block that
