@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "common.hpp"
+#include "train_internal.hpp"
 
 namespace pwclo {
 

@@ -18,8 +18,6 @@ bool check_launch(const char *what);  // hipGetLastError() -> sticky error; true
 // partial[(ch * nsplit + s) * 2 + {sum, sum of squares}] over M elements per channel (conv1x1.hip's statistics epilogue)
 void bn_forward_finish_launch(int c, int nsplit, long long M, float eps, float momentum, const double *partial,
                               float *running_mean, float *running_var, float *save_mean, float *save_invstd);
-// dgamma[ch] = sum of the partials' second entries, dbeta[ch] = sum of the first (conv1x1.hip's input-gradient epilogue)
-void bn_backward_finish_launch(int c, int nsplit, const double *partial, float *dgamma, float *dbeta);
 // Device view of the library's pinned error word (state.hip): a kernel stores a PWCLO_E* code there with a
 // system-scope atomic; pwclo_last_error() picks it up.  nullptr (and a sticky error) if it cannot be allocated.
 unsigned *device_error_word();

@@ -17,6 +17,7 @@
 #include <mutex>
 
 #include "common.hpp"
+#include "train_internal.hpp"
 
 namespace pwclo {
 
