@@ -259,6 +259,15 @@ void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int c2, int w1
                                     const float *src0, const float *src1, const float *src2,
                                     const float *packed_w, float *out);
 
+/* The same two-layer stack followed by ONE linear layer (w2 -> wt channels, bias, no activation) applied to the stack's
+ * output while it is in registers and written to out_tail (b,s,wt): the hoisted partial product W1_feat . out + b1 that the
+ * next refinement level's set-upconv (pointnet2_modules.py:479-506, first layer of its mlp) would otherwise request from
+ * linear_jobs_kernel_wrapper (section 4); same rows bit for bit.  packed_tail holds tail_floats floats. */
+void pointwise_tail_fused_kernel_wrapper(int b, int s, int c0, int c1, int c2, int w1, int w2, int wt,
+                                         const float *src0, const float *src1, const float *src2,
+                                         const float *packed_w, const float *packed_tail, float *out,
+                                         float *out_tail, int tail_floats);
+
 /* CostVolume.forward (PW/costvolume.py:63-190) in three launches.
  * a1: per (query s, neighbour k) pixel: mlp_convs([geometry10 | feat1[s] | feat2[idx]]) -> pix
  *     (b, s*pix_slots, 64).  pix_slots is the CALLER's choice (it allocates pix) and must be passed identically
@@ -488,7 +497,7 @@ void conv1x1_wgrad_kernel_wrapper(int b, int cin, int cout, int p, const float *
  * point by linear_jobs and gathered by the pixel kernels as accumulator seeds (csrc/mlp_core.hpp,
  * "Hoisting").  Same results as section 3 up to fp32 summation order. */
 
-/* Up to 6 independent per-point linear maps in one launch: out_j (npts_j, cout_j) = src_j (npts_j,
+/* Up to 8 independent per-point linear maps in one launch: out_j (npts_j, cout_j) = src_j (npts_j,
  * cin_j) . W_j^T + bias_j, no activation; cin in {16,32,64}, cout in {16,32,64,128}; all seven
  * arrays are HOST arrays of length njobs (pointers inside are device pointers). */
 void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int *cin, const int *cout,

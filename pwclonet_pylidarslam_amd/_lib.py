@@ -95,6 +95,7 @@ SIGNATURES = {
     "group_points_grad_sorted_strided_kernel_wrapper": ([_i, _i, _i, _i, _i, _F, ctypes.c_longlong, _F, _F, _F], None),
     "upconv_fused_kernel_wrapper": ([_i] * 4 + [_F] * 6, None),
     "pointwise_fused_kernel_wrapper": ([_i] * 7 + [_F] * 5, None),
+    "pointwise_tail_fused_kernel_wrapper": ([_i] * 8 + [_F] * 7 + [_i], None),
     "cv_fused_a1_kernel_wrapper": ([_i] * 5 + [_F] * 7 + [_i], None),
     "cv_fused_a2_kernel_wrapper": ([_i] * 4 + [_F] * 6 + [_i] * 3, None),
     "cv_fused_b_kernel_wrapper": ([_i] * 4 + [_F] * 6, None),

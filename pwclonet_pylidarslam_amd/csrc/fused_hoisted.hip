@@ -64,7 +64,8 @@ struct LinJob {
   int npts, nbi, nbo;
   int out_bf16;
 };
-struct LinArgs { LinJob job[6]; };
+constexpr int LIN_MAX_JOBS = 8;
+struct LinArgs { LinJob job[LIN_MAX_JOBS]; };
 constexpr int LIN_WAVES = 8;
 
 template <int NBI, int NBO>
@@ -711,7 +712,7 @@ extern "C" void linear_jobs_kernel_wrapper(int njobs, const int *npts, const int
                                            const float *const *src, const float *const *w,
                                            float *const *out, const int *out_bf16) {
   if (njobs <= 0) return;
-  PWCLO_REQUIRE(njobs <= 6, "linear_jobs: at most 6 jobs per launch (got %d)", njobs);
+  PWCLO_REQUIRE(njobs <= LIN_MAX_JOBS, "linear_jobs: at most %d jobs per launch (got %d)", LIN_MAX_JOBS, njobs);
   LinArgs a;
   int max_tiles = 1, max_lds = 0;
   for (int i = 0; i < njobs; ++i) {
@@ -910,8 +911,10 @@ extern "C" void cv_fused_a_lane6_kernel_wrapper(int b, int n, int s, const float
   constexpr int lds = 4 * (fa1 + fa2);
   static_assert(lds <= 160 * 1024, "both stages' weights must fit the 160 KiB of LDS");
   const long long t16 = (long long)b * ((s + 15) / 16);
-  static bool attr = false, attr_v = false;
-  if (packed_v2 != nullptr) launch_h<8>(cv_a_lane6_kernel<8, true>, attr_v, lds, t16, a);
+  static bool attr = false, attr_v = false, attr_v4 = false;
+  // a coarse level's few hundred tiles: 4-wave workgroups spread them over twice the CUs
+  if (packed_v2 != nullptr && t16 <= 1024) launch_h<4>(cv_a_lane6_kernel<4, true>, attr_v4, lds, t16, a);
+  else if (packed_v2 != nullptr) launch_h<8>(cv_a_lane6_kernel<8, true>, attr_v, lds, t16, a);
   else launch_h<8>(cv_a_lane6_kernel<8, false>, attr, lds, t16, a);
   check_launch("cv_fused_a_lane6");
 }

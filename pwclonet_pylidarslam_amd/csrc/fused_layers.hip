@@ -162,17 +162,26 @@ struct PointwiseArgs {
   float *out;           // (B,S,16*BOUT)
   int B, S;
   int stagger;
+  const float *w_tail;  // BT > 0: packed single layer 16*B2 -> 16*BT, no activation (a consumer's hoisted partial product)
+  float *out_tail;      // BT > 0: (B,S,16*BT)
 };
 
-template <int NB0, int NB1, int NB2, int B1, int B2 /*0 = single layer*/, int P, int W>
+// BT > 0: the linear map a consumer of this stack's output would otherwise get from linear_jobs (the next refinement
+// level's set-upconv seeds W1_feat . out + b1) runs as a third layer while the output is in registers -- the accumulators
+// of layer 2 are its B operands -- with its tiles LDS resident beside the stack's; same routine, operands and k order as
+// linear_jobs_kernel: bit-identical rows.
+template <int NB0, int NB1, int NB2, int B1, int B2 /*0 = single layer*/, int P, int W, int BT = 0>
 __global__ __launch_bounds__(W * 64) void pointwise_kernel(PointwiseArgs a) {
   TraceScope trace_scope_(TK_POINTWISE);
   constexpr int NBI = NB0 + NB1 + NB2;
   constexpr int W1 = layer_floats(NBI, B1);
   constexpr int W2 = B2 > 0 ? layer_floats(B1, B2) : 0;
+  constexpr int WT = BT > 0 ? layer_floats(B2, BT) : 0;
   constexpr int BOUT = B2 > 0 ? B2 : B1;
+  static_assert(BT == 0 || B2 > 0, "the tail follows a two-layer stack");
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
   stage_weights(lds_w, a.w, W1 + W2);
+  if constexpr (BT > 0) stage_weights(lds_w + W1 + W2, a.w_tail, WT);
   __syncthreads();
   stagger_start(threadIdx.x >> 6, (NBI * B1 + B1 * B2) * 4 * P, a.stagger);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
@@ -204,6 +213,16 @@ __global__ __launch_bounds__(W * 64) void pointwise_kernel(PointwiseArgs a) {
           if (sq[p] >= 0)
             *reinterpret_cast<f32x4 *>(at32(a.out, ((unsigned)b * (unsigned)a.S + (unsigned)sq[p]) * (unsigned)(64 * BOUT) +
                                                         64u * o + 16u * (unsigned)g)) = h2[o][p];
+      if constexpr (BT > 0) {
+        f32x4 ht[BT][P];
+        mlp_layer<B2, BT, P, false>(ht, h2, lds_w + W1 + W2, lane);
+#pragma unroll
+        for (int o = 0; o < BT; ++o)
+#pragma unroll
+          for (int p = 0; p < P; ++p)
+            if (sq[p] >= 0)
+              st_group<false>(a.out_tail, (unsigned)b * (unsigned)a.S + (unsigned)sq[p], 16u * BT, o, g, ht[o][p]);
+      }
     } else {
 #pragma unroll
       for (int o = 0; o < B1; ++o)
@@ -790,7 +809,7 @@ extern "C" void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int
                                                const float *packed_w, float *out) {
   if (b <= 0 || s <= 0) return;
   PWCLO_REQUIRE(rows_fit_32bit((long long)b * s), "pointwise_fused: batch too large for 32-bit offsets (b=%d)", b);
-  PointwiseArgs a{{src0, src1, src2}, packed_w, out, b, s, fl_tuning("PWCLO_FL_STAGGER", 0)};
+  PointwiseArgs a{{src0, src1, src2}, packed_w, out, b, s, fl_tuning("PWCLO_FL_STAGGER", 0), nullptr, nullptr};
 #define PW_CASE(C0, C1, C2, A1, A2)                                                                 \
   if (c0 == C0 && c1 == C1 && c2 == C2 && w1 == A1 && w2 == A2) {                                   \
     static bool attr = false, attr1 = false, attr4 = false;                                         \
@@ -820,6 +839,39 @@ extern "C" void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int
 #undef PW_CASE
   set_error(PWCLO_EINVAL, "pointwise_fused: no kernel for sources (%d,%d,%d) widths (%d,%d)", c0, c1, c2,
             w1, w2);
+}
+
+// The same stack followed by one linear layer (w2 -> wt channels, no activation) written to out_tail (b,s,wt): the
+// hoisted partial product a consumer would otherwise request from linear_jobs_kernel_wrapper (see pointwise_kernel).
+extern "C" void pointwise_tail_fused_kernel_wrapper(int b, int s, int c0, int c1, int c2, int w1, int w2, int wt,
+                                                    const float *src0, const float *src1, const float *src2,
+                                                    const float *packed_w, const float *packed_tail, float *out,
+                                                    float *out_tail, int tail_floats) {
+  if (b <= 0 || s <= 0) return;
+  PWCLO_REQUIRE(rows_fit_32bit((long long)b * s), "pointwise_tail_fused: batch too large for 32-bit offsets (b=%d)", b);
+  PWCLO_REQUIRE(packed_tail != nullptr && out_tail != nullptr, "pointwise_tail_fused: the tail needs its packed layer and an output");
+  PointwiseArgs a{{src0, src1, src2}, packed_w, out, b, s, 0, packed_tail, out_tail};
+#define PWT_CASE(C0, C1, C2, A1, A2, AT)                                                            \
+  if (c0 == C0 && c1 == C1 && c2 == C2 && w1 == A1 && w2 == A2 && wt == AT) {                       \
+    static bool attr16 = false, attr4 = false;                                                      \
+    constexpr int NBI = (C0 + C1 + C2) / 16;                                                        \
+    constexpr int lds = 4 * (layer_floats(NBI, A1 / 16) + layer_floats(A1 / 16, A2 / 16) + layer_floats(A2 / 16, AT / 16)); \
+    static_assert(lds <= 160 * 1024, "stack and tail must fit the 160 KiB of LDS");                 \
+    PWCLO_REQUIRE(tail_floats == layer_floats(A2 / 16, AT / 16), "pointwise_tail_fused: packed tail holds %d floats, needs %d", \
+                  tail_floats, layer_floats(A2 / 16, AT / 16));                                     \
+    if (fl_tuning("PWCLO_COARSE_W4", 1) && tiles_of(b, s, 1, 1) <= 2048)                            \
+      launch_persistent<4>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 4, AT / 16>, \
+                           attr4, lds, tiles_of(b, s, 1, 1), a);                                    \
+    else launch_persistent<16>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 16, AT / 16>, \
+                               attr16, lds, tiles_of(b, s, 1, 1), a);                               \
+    check_launch("pointwise_tail_fused");                                                           \
+    return;                                                                                         \
+  }
+  PWT_CASE(32, 64, 64, 128, 64, 128)   // features predictor, level 2 (+ level 1's set-upconv seeds)
+  PWT_CASE(64, 64, 32, 128, 64, 128)   // mask predictor, level 2
+#undef PWT_CASE
+  set_error(PWCLO_EINVAL, "pointwise_tail_fused: no kernel for sources (%d,%d,%d) widths (%d,%d) tail %d", c0, c1, c2,
+            w1, w2, wt);
 }
 
 extern "C" void cv_fused_a1_kernel_wrapper(int b, int n, int s, int k, int c, const float *xyz1,

@@ -346,6 +346,27 @@ class FusedPointwise:
                   _p(src[0]), _p(src[1]), _p(src[2]), _p(self.packed), _p(out))
         return out
 
+    # source layouts for which csrc/fused_layers.hip has a stack + linear-tail kernel (stack and tail fit the 160 KiB of LDS)
+    TAIL_CASES = {(32, 64, 64, 128, 64), (64, 64, 32, 128, 64)}
+
+    def tail_supported(self, job):
+        return ((*self.src_c, self.w1, self.w2) in self.TAIL_CASES and job.cin == self.c_out and job.cout == 128
+                and not job.out_bf16)
+
+    def with_tail(self, job, *sources):
+        """``(self(*sources), run_linear_jobs([(job, out)])[0])`` as ONE launch: `job` (a consumer's hoisted partial
+        product, e.g. the next refinement level's set-upconv seeds) runs as a third layer on the output in registers."""
+        B, S, _ = sources[0].shape
+        src = list(sources) + [None] * (3 - len(sources))
+        out = torch.empty((B, S, self.c_out), dtype=torch.float32, device=sources[0].device)
+        tail = torch.empty((B, S, job.cout), dtype=torch.float32, device=sources[0].device)
+        _lib.annotate(family="mlp", flops=2.0 * B * S * (self.macs + job.cin * job.cout),
+                      bytes=4.0 * B * S * (self.c_in + self.c_out + job.cout))
+        _lib.call("pointwise_tail_fused_kernel_wrapper", out.device, B, S, *self.src_c, self.w1, self.w2, job.cout,
+                  _p(src[0]), _p(src[1]), _p(src[2]), _p(self.packed), _p(job.packed), _p(out), _p(tail),
+                  job.packed.numel())
+        return out, tail
+
 
 # ---- set-upconv ----------------------------------------------------------------------------------------
 
@@ -498,11 +519,11 @@ class LinearJob:
 
 def run_linear_jobs(jobs):
     """jobs: list of (LinearJob, src (B,N,cin) contiguous) -> list of (B,N,cout) tensors, one launch
-    per <= 6 jobs."""
+    per <= 8 jobs."""
     import ctypes
     outs = []
-    for start in range(0, len(jobs), 6):
-        chunk = jobs[start:start + 6]
+    for start in range(0, len(jobs), 8):
+        chunk = jobs[start:start + 8]
         n = len(chunk)
         srcs = [s_ for _, s_ in chunk]
         res = [torch.empty(s_.shape[:-1] + (j.cout,), dtype=torch.bfloat16 if j.out_bf16 else torch.float32,
@@ -738,7 +759,8 @@ class FusedCostVolumeHoisted:
         if idx_q is None:
             idx_q = knn(kq, xyz2, xyz1)
         kp = self.kp
-        merged = (kp == 6 and kq == 6 and self.wfmt == WFMT_F32 and self.wfmt_a2 == WFMT_F32 and B * ((S + 15) // 16) > 1024
+        merged = (kp == 6 and kq == 6 and self.wfmt == WFMT_F32 and self.wfmt_a2 == WFMT_F32
+                  and B * ((S + 15) // 16) >= int(os.environ.get("PWCLO_CV_MERGED_MIN", "1025"))
                   and os.environ.get("PWCLO_LANE6", "1") != "0" and os.environ.get("PWCLO_CV_MERGED", "1") != "0")
         if merged:
             return self._merged(xyz1, xyz2, u, v, u2, idx_q, idx, taps, tap)
@@ -769,7 +791,8 @@ class FusedCostVolumeHoisted:
         fold_v2 = os.environ.get("PWCLO_CV_V2", "1") != "0" and not self.job_v2.out_bf16
         first = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
         v2 = torch.empty((B, S, 128), dtype=torch.float32, device=dev) if fold_v2 else None
-        _lib.annotate(family="mlp", kernel="cv_a_lane6_kernel<8, %s>" % ("true" if fold_v2 else "false"),
+        _lib.annotate(family="mlp", kernel="cv_a_lane6_kernel<%d, %s>" % (4 if fold_v2 and B * ((S + 15) // 16) <= 1024 else 8,
+                                                                          "true" if fold_v2 else "false"),
                       flops=2.0 * B * S * (6 * (self.macs_a1 - 2 * self.c * 128 + self.macs_a2) + (64 * 128 if fold_v2 else 0)),
                       bytes=4.0 * B * (S * 6 * (1 + 3 + 128) + S * (3 + 3 * 128 + 64 + (128 if fold_v2 else 0))))
         _lib.call("cv_fused_a_lane6_kernel_wrapper", dev, B, N, S, _p(xyz1), _p(u), _p(xyz2), _p(v), _p(idx_q),
@@ -881,18 +904,27 @@ class FusedPWCLONet:
             self.pwr.append(d)
 
     def _refine(self, br, d, row, pose, x1, f1, x2, f2, x1_prev, emb_prev, mask_prev, q_prev, t_prev,
-                taps=None, tap="", warped=None, warp_next=None, st_up=None, st_q=None):
+                taps=None, tap="", warped=None, warp_next=None, st_up=None, st_q=None, cvj=None, pres=None, nxt=None,
+                carry=None):
         """``warped``: quat_warp_pm(x1, q_prev, t_prev) when the previous level's pose head already produced it;
         ``warp_next``: the next (finer) level's cloud, warped by this level's head with the pose it composes (returned as a
         fifth value).  ``st_up`` / ``st_q``: search structures (``knn_keep``) the pyramid built for the 2B clouds that
-        x1_prev (frame 1: clouds [0, B)) and x2 (frame 2: clouds [B, 2B)) belong to, or None."""
+        x1_prev (frame 1: clouds [0, B)) and x2 (frame 2: clouds [B, 2B)) belong to, or None.
+        Hoisted partial products that something earlier already produced: ``cvj`` = (u, v, u2) of this level's cost volume
+        (they need the pyramid features only: ``rest`` computes them beside the set abstractions' seeds), ``pres`` = (pre_f,
+        pre_m), the set-upconv seeds (written by the previous level's flow predictors as a linear tail).  ``nxt`` = the next
+        (finer) level's modules: when given, this level's predictors write that level's seeds into ``carry["pres"]``."""
         B = x1.shape[0]
         idx_up = br.hold(knn_on(st_up, 0, 8, x1) if st_up is not None and x1.shape[1] >= 256 else knn(8, x1_prev, x1))
         if taps is not None:
             taps[tap + ".up.idx"] = idx_up
-        if self.hoist:          # all per-point partial products of this level in one launch
-            pre_f, pre_m, u, v, u2 = br.hold(*run_linear_jobs(
-                d["up_f"].jobs(emb_prev) + d["up_m"].jobs(mask_prev) + d["cv"].jobs(f1, f2)))
+        if self.hoist:          # the per-point partial products of this level nobody has produced yet, in one launch
+            jobs = ([] if pres is not None else d["up_f"].jobs(emb_prev) + d["up_m"].jobs(mask_prev)) + \
+                   ([] if cvj is not None else d["cv"].jobs(f1, f2))
+            outs = run_linear_jobs(jobs) if jobs else []
+            br.hold(*outs, None)
+            pre_f, pre_m = pres if pres is not None else outs[:2]
+            u, v, u2 = cvj if cvj is not None else outs[-3:]
         one_launch = self.hoist and upconv_post_supported((d["up_f"], d["up_m"]), x1.shape[0], x1.shape[1])
         if one_launch:          # both set-upconvs and their post-MLPs as one launch, beside the warp -> cost-volume chain
             with br.fork(1):
@@ -914,8 +946,14 @@ class FusedPWCLONet:
         br.join(1)
         if not one_launch:
             br.join(2)
-        emb = d["pred_f"](f1, resid, up_feat)
-        mask = up_mask if d["last"] else d["pred_m"](up_mask, emb, f1)
+        if (nxt is not None and carry is not None and not d["last"] and d["pred_f"].tail_supported(nxt["up_f"].pre_job)
+                and d["pred_m"].tail_supported(nxt["up_m"].pre_job)):
+            emb, pre_f_next = d["pred_f"].with_tail(nxt["up_f"].pre_job, f1, resid, up_feat)
+            mask, pre_m_next = d["pred_m"].with_tail(nxt["up_m"].pre_job, up_mask, emb, f1)
+            carry["pres"] = br.hold(pre_f_next, pre_m_next)
+        else:
+            emb = d["pred_f"](f1, resid, up_feat)
+            mask = up_mask if d["last"] else d["pred_m"](up_mask, emb, f1)
         if warp_next is not None:
             q, t, w_next = br.hold(*d["head"](emb, mask, pose, row, q_prev, t_prev, warp_next=warp_next))
             return q, t, emb, mask, w_next
@@ -986,6 +1024,10 @@ class FusedPWCLONet:
         built = {}                       # pyramid level -> search structure of its 2B clouds (knn_keep)
         # neighbour lists of every knn call (tests compare them with the oracle's); only when asked for
         taps = {} if return_intermediates else None
+        early_users, cvj = {}, {}
+        if self.hoist and os.environ.get("PWCLO_EARLY_CV", "1") != "0":
+            early_users = {1: [self.pwr[2]["cv"]], 2: [self.pwr[1]["cv"]], 3: [self.cv3, self.pwr[0]["cv"]]}
+        tails = self.hoist and os.environ.get("PWCLO_PW_TAIL", "1") != "0"
         for lvl, (fsa, (npoint, nsample)) in enumerate(zip(self.sa, self.sa_cfg)):
             br.wait(ready[lvl])
             new_x = samples[lvl]
@@ -1004,7 +1046,19 @@ class FusedPWCLONet:
             if taps is not None:
                 taps["psa_%d.knn_idx" % (lvl + 1)] = idx
             if self.hoist:
-                pre = br.hold(run_linear_jobs(fsa.jobs(f))[0]) if f is not None else None
+                pre = None
+                if f is not None:
+                    jobs = fsa.jobs(f)
+                    # `f` = the features of pyramid level `lvl` (both frames): the partial products the cost volumes take
+                    # from them depend on nothing else -- same launch as this level's set-abstraction seeds
+                    users = early_users.get(lvl, [])
+                    for cv in users:
+                        jobs = jobs + cv.jobs(f[:B], f[B:])
+                    outs = run_linear_jobs(jobs)
+                    br.hold(*outs, None)
+                    pre = outs[0]
+                    for i, cv in enumerate(users):
+                        cvj[id(cv)] = tuple(outs[1 + 3 * i:4 + 3 * i])
                 f = br.hold(fsa(x, new_x, pre, idx))
             else:
                 f = br.hold(fsa(x, new_x, f, idx))
@@ -1016,7 +1070,7 @@ class FusedPWCLONet:
         # flow_feature_encoding samples the same cloud as psa_4(frame 1): reuse x14
         idx_ffe = knn(self.ffe_cfg[1], x13, x14)
         if self.hoist:
-            flow = self.cv3(x13, x23, *run_linear_jobs(self.cv3.jobs(f13, f23)), taps=taps, tap="cv3")
+            flow = self.cv3(x13, x23, *(cvj.get(id(self.cv3)) or run_linear_jobs(self.cv3.jobs(f13, f23))), taps=taps, tap="cv3")
             emb4 = self.ffe(x13, x14, run_linear_jobs(self.ffe.jobs(flow))[0], idx_ffe)
         else:
             flow = self.cv3(x13, f13, x23, f23, taps=taps, tap="cv3")
@@ -1028,20 +1082,25 @@ class FusedPWCLONet:
         if os.environ.get("PWCLO_HEAD_WARP", "1") != "0":
             # every pose head also warps the next finer cloud with the pose it has just composed (one launch fewer per level)
             q4, t4, w3 = br.hold(*self.l4_head(emb4, mask4, pose, 3, warp_next=x13))
+            c3, c2 = {}, {}
             q3, t3, emb3, mask3, w2 = self._refine(br, self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4,
-                                                   taps, "pwr3", warped=w3, warp_next=x12, st_up=built.get(4), st_q=built.get(3))
+                                                   taps, "pwr3", warped=w3, warp_next=x12, st_up=built.get(4), st_q=built.get(3),
+                                                   cvj=cvj.get(id(self.pwr[0]["cv"])), nxt=self.pwr[1] if tails else None, carry=c3)
             q2, t2, emb2, mask2, w1 = self._refine(br, self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3,
-                                                   taps, "pwr2", warped=w2, warp_next=x11, st_up=built.get(3), st_q=built.get(2))
+                                                   taps, "pwr2", warped=w2, warp_next=x11, st_up=built.get(3), st_q=built.get(2),
+                                                   cvj=cvj.get(id(self.pwr[1]["cv"])), pres=c3.get("pres"),
+                                                   nxt=self.pwr[2] if tails else None, carry=c2)
             q1, t1, emb1, mask1 = self._refine(br, self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2,
-                                               taps, "pwr1", warped=w1, st_up=built.get(2), st_q=built.get(1))
+                                               taps, "pwr1", warped=w1, st_up=built.get(2), st_q=built.get(1),
+                                               cvj=cvj.get(id(self.pwr[2]["cv"])), pres=c2.get("pres"))
         else:
             q4, t4 = self.l4_head(emb4, mask4, pose, 3)
             q3, t3, emb3, mask3 = self._refine(br, self.pwr[0], 2, pose, x13, f13, x23, f23, x14, emb4, mask4, q4, t4,
-                                               taps, "pwr3", st_up=built.get(4), st_q=built.get(3))
+                                               taps, "pwr3", st_up=built.get(4), st_q=built.get(3), cvj=cvj.get(id(self.pwr[0]["cv"])))
             q2, t2, emb2, mask2 = self._refine(br, self.pwr[1], 1, pose, x12, f12, x22, f22, x13, emb3, mask3, q3, t3,
-                                               taps, "pwr2", st_up=built.get(3), st_q=built.get(2))
+                                               taps, "pwr2", st_up=built.get(3), st_q=built.get(2), cvj=cvj.get(id(self.pwr[1]["cv"])))
             q1, t1, emb1, mask1 = self._refine(br, self.pwr[2], 0, pose, x11, f11, x21, f21, x12, emb2, mask2, q2, t2,
-                                               taps, "pwr1", st_up=built.get(2), st_q=built.get(1))
+                                               taps, "pwr1", st_up=built.get(2), st_q=built.get(1), cvj=cvj.get(id(self.pwr[2]["cv"])))
         if return_intermediates:
             return pose, dict(x11=x11, f11=f11, f13=f13, flow=flow, emb4=emb4, mask4=mask4, emb3=emb3,
                               mask3=mask3, emb2=emb2, mask2=mask2, emb1=emb1, mask1=mask1, q=(q1, q2, q3, q4),

@@ -177,6 +177,77 @@ def test_fused_cost_volume_first_aggregate_as_one_kernel(cuda, monkeypatch, c, s
     assert torch.equal(outs["merged+v2"], outs["separate"])
 
 
+def test_fused_cost_volume_one_kernel_at_a_coarse_level(cuda, monkeypatch):
+    """Refinement level 3 at batch 32 (512 query tiles): the one-kernel first aggregate runs there too, as 4-wave
+    workgroups (cv_a_lane6_kernel<4, true>), v2 from its epilogue.  The kernels it replaces at that size (cv_a1_h +
+    cv_a2_dense6 + linear_jobs) sum the soft-max in a different order: compared at the fused layers' bound, and bit for bit
+    with the 8-wave form of the same kernel (selected by a larger batch of the same clouds)."""
+    name = "pose_warp_refinement_3.cost_volume"
+    mod, _ = filled(CostVolume(nsample=4, nsample_q=6, in_channel1=64, in_channel2=64, mlp1=[128, 64, 64], mlp2=[128, 64]), name)
+    g = torch.Generator().manual_seed(26)
+    b, s, n = 32, 256, 250
+    x1, x2 = cloud(27, b, s).to(cuda), cloud(28, b, n).to(cuda)
+    p1, p2 = torch.randn(b, s, 64, generator=g).to(cuda), torch.randn(b, n, 64, generator=g).to(cuda)
+    cv = fused.FusedCostVolumeHoisted(mod.to(cuda))
+    u, v, u2 = fused.run_linear_jobs(cv.jobs(p1, p2))
+    idx_q, idx = fused.knn(6, x2, x1), fused.knn(4, x1, x1)
+    monkeypatch.setenv("PWCLO_CV_MERGED_MIN", "512")
+    merged = cv(x1, x2, u, v, u2, idx_q=idx_q, idx=idx)
+    monkeypatch.setenv("PWCLO_CV_MERGED", "0")
+    separate = cv(x1, x2, u, v, u2, idx_q=idx_q, idx=idx)
+    close(merged, separate)
+    monkeypatch.setenv("PWCLO_CV_MERGED", "1")
+    rep = lambda t: torch.cat([t] * 3).contiguous()          # 1536 tiles: the 8-wave workgroups
+    wide = cv(rep(x1), rep(x2), rep(u), rep(v), rep(u2), idx_q=rep(idx_q), idx=rep(idx))
+    assert torch.equal(wide[:b], merged) and torch.equal(wide[2 * b:], merged)
+
+
+def test_pointwise_stack_with_linear_tail_and_eight_linear_jobs(cuda):
+    """pointwise_tail_fused (csrc/fused_layers.hip): a flow predictor that also writes the next level's set-upconv seeds is,
+    bit for bit, the predictor followed by linear_jobs; linear_jobs takes 8 jobs per launch."""
+    g = torch.Generator().manual_seed(19)
+    job = fused.LinearJob(torch.randn(128, 64, generator=g).to(cuda) * 0.2, torch.randn(128, generator=g).to(cuda))
+    for chans, b, s in (((32, 64, 64), 3, 1000), ((64, 64, 32), 2, 77), ((32, 64, 64), 40, 1024)):
+        fp, _ = filled(FlowPredictor(in_channel=sum(chans), mlp=[128, 64]), "l4_flow_predictor")
+        pw = fused.FusedPointwise(fp.to(cuda).mlp_convs, list(chans))
+        assert pw.tail_supported(job)
+        srcs = [torch.randn(b, s, c, generator=g).to(cuda) for c in chans]
+        out = pw(*srcs)
+        (ref_tail,) = fused.run_linear_jobs([(job, out)])
+        out2, tail = pw.with_tail(job, *srcs)
+        assert torch.equal(out2, out) and torch.equal(tail, ref_tail)
+    fp, _ = filled(FlowPredictor(in_channel=192, mlp=[128, 64]), "l4_flow_predictor")
+    assert not fused.FusedPointwise(fp.to(cuda).mlp_convs, [64, 64, 64]).tail_supported(job)   # 165 KB: beyond the LDS
+    jobs = []
+    for i, (cin, cout, npts) in enumerate([(16, 128, 500), (32, 64, 33), (64, 128, 2048), (64, 16, 7), (16, 16, 100),
+                                           (32, 128, 999), (64, 64, 64), (16, 32, 4097)]):
+        j = fused.LinearJob(torch.randn(cout, cin, generator=g).to(cuda), torch.randn(cout, generator=g).to(cuda))
+        jobs.append((j, torch.randn(1, npts, cin, generator=g).to(cuda)))
+    together = fused.run_linear_jobs(jobs)
+    for (j, src), got in zip(jobs, together):
+        assert torch.equal(got, fused.run_linear_jobs([(j, src)])[0])
+
+
+def test_early_partial_products_and_predictor_tails_leave_the_forward_unchanged(cuda, monkeypatch):
+    """fused.FusedPWCLONet.rest: the cost volumes' feature-only partial products computed beside the set abstractions' seeds
+    (PWCLO_EARLY_CV) and the set-upconv seeds written by the previous level's flow predictors (PWCLO_PW_TAIL) are the same
+    rows as the per-level linear_jobs launches they replace: bit-identical poses and intermediates."""
+    pc1, pc2, _, _ = synthetic.kitti_like_pair(43, 4096, 2)
+    x1 = torch.from_numpy(pc1[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    x2 = torch.from_numpy(pc2[:, :, :3]).permute(0, 2, 1).contiguous().to(cuda)
+    fnet = fused.FusedPWCLONet(_net(cuda))
+    pose, inter = fnet(x1, x2, return_intermediates=True)
+    for env in ({"PWCLO_EARLY_CV": "0"}, {"PWCLO_PW_TAIL": "0"}, {"PWCLO_EARLY_CV": "0", "PWCLO_PW_TAIL": "0"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        pose2, inter2 = fnet(x1, x2, return_intermediates=True)
+        assert torch.equal(pose2, pose), env
+        for key in ("flow", "emb4", "emb3", "mask3", "emb2", "mask2", "emb1", "mask1"):
+            assert torch.equal(inter2[key], inter[key]), (env, key)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+
+
 @pytest.mark.parametrize("n,s,k", [(2048, 2048, 6), (1024, 2048, 8), (1024, 1000, 6), (300, 256, 8)])
 def test_knn_search_on_a_slice_of_a_kept_structure(cuda, n, s, k):
     """fused.knn_keep / knn_on (csrc/knn.hip knn_point_prebuilt_slice): the structure built once for the pyramid's 2B clouds
