@@ -1045,6 +1045,7 @@ class FusedPWCLONet:
                 idx = br.hold(knn(nsample, x, new_x))
             if taps is not None:
                 taps["psa_%d.knn_idx" % (lvl + 1)] = idx
+            idx_last = idx
             if self.hoist:
                 pre = None
                 if f is not None:
@@ -1068,7 +1069,11 @@ class FusedPWCLONet:
         (x21, f21), (x22, f22), (x23, f23), _ = [(a[B:], b[B:]) for a, b in lv]
 
         # flow_feature_encoding samples the same cloud as psa_4(frame 1): reuse x14
-        idx_ffe = knn(self.ffe_cfg[1], x13, x14)
+        if self.ffe_cfg == self.sa_cfg[3] and os.environ.get("PWCLO_FFE_REUSE", "1") != "0":
+            # same search as psa_4's on frame 1 (queries x14 among x13, same nsample; clouds are searched independently)
+            idx_ffe = idx_last[:B]
+        else:
+            idx_ffe = knn(self.ffe_cfg[1], x13, x14)
         if self.hoist:
             flow = self.cv3(x13, x23, *(cvj.get(id(self.cv3)) or run_linear_jobs(self.cv3.jobs(f13, f23))), taps=taps, tap="cv3")
             emb4 = self.ffe(x13, x14, run_linear_jobs(self.ffe.jobs(flow))[0], idx_ffe)

@@ -1,22 +1,24 @@
 #!/bin/bash
-# Developer A/B of the round-3 launch folds (early cv partial products, predictor tails, one-kernel cost volume at level 3).
-set -e
-O=gpurun_out/r3b
+# Developer A/B (round 3, second session): full GPU suite, then in-flight depth sweeps of configs[1] (batch 1) and configs[2].
+O=gpurun_out/r3c
 mkdir -p $O
-python -m pytest tests/test_gpu_fused.py tests/test_gpu_config2.py -x -q > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
+python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
 tail -3 $O/tests.log
-python tools/launch_table.py > $O/lt_new.txt 2>&1
-PWCLO_CV_MERGED_MIN=1025 python tools/launch_table.py > $O/lt_merged_min1025.txt 2>&1
-PWCLO_CV_MERGED_MIN=1025 PWCLO_EARLY_CV=0 PWCLO_PW_TAIL=0 python tools/launch_table.py > $O/lt_old.txt 2>&1
-B="--no-cpu-baseline --no-configs --no-variants"
-python bench.py $B > $O/bench_new.json 2> $O/bench_new.err
-PWCLO_CV_MERGED_MIN=1025 python bench.py $B > $O/bench_merged_min1025.json 2> $O/bench_b.err
-PWCLO_CV_MERGED_MIN=1025 PWCLO_EARLY_CV=0 PWCLO_PW_TAIL=0 python bench.py $B > $O/bench_old.json 2> $O/bench_c.err
-python bench.py $B > $O/bench_new2.json 2> $O/bench_new2.err
-for f in new merged_min1025 old new2; do python - <<PY
-import json
-d=json.loads(open("$O/bench_$f.json").read().strip().splitlines()[-1])
-print("$f", round(d["value"]), d["ms_per_step"], d["roofline"]["mlp_family"]["ms_per_step"], d["roofline"]["mlp_family"]["launches_per_step"], d["roofline"]["mlp_family"]["frac"])
-PY
+B="--no-cpu-baseline --no-configs --no-variants --no-roofline --timed-seconds 1.5"
+for d in 4 8 12 16; do
+  python bench.py --batch 1 --inflight $d $B > $O/b1_inflight$d.json 2> $O/b1_inflight$d.err || echo "b1 inflight $d failed"
 done
-tail -1 $O/lt_new.txt $O/lt_merged_min1025.txt $O/lt_old.txt
+for d in 3 4 5 6 8; do
+  python bench.py --inflight $d $B > $O/b32_inflight$d.json 2> $O/b32_inflight$d.err || echo "b32 inflight $d failed"
+done
+python bench.py --pipeline staged --inflight 4 $B > $O/b32_staged4.json 2> $O/b32_staged4.err || echo "staged failed"
+python bench.py --batch 4 --inflight 8 $B > $O/b4_inflight8.json 2> $O/b4_inflight8.err || echo "b4 failed"
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("$O/b*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("/")[-1], round(d["value"]), round(d["ms_per_step"], 4), d["config"].get("batches_in_flight"))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
