@@ -127,7 +127,7 @@ struct SAHArgs {
 // KMAJ (level 0 only): layers 1 and 2 produce their <= 8 real channels "k-step major" (fused.py: pack_layer
 // kmajor_out), so layers 2 and 3 run only the two k-steps that carry data.
 template <int B1, int B2, int B3, int KP, int P, int W, bool XYZ_ONLY, int FMT = 0, bool KMAJ = false>
-__global__ __launch_bounds__(W * 64) void sa_h_kernel(SAHArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void sa_h_kernel(SAHArgs a) {
   TraceScope trace_scope_(TK_SA_H);
   constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<FMT>(B1, B2), W3 = layer_floats_any<FMT>(B2, B3);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -210,7 +210,7 @@ struct UpHArgs {
 };
 
 template <int KP, int P, int W, int FMT = 0>
-__global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void upconv_h_kernel(UpHArgs a) {
   TraceScope trace_scope_(TK_UPCONV_H);
   constexpr int B1 = 8, B2 = 4;
   constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<FMT>(B1, B2);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(W * 64) void upconv_h_kernel(UpHArgs a) {
 // queries, pass k runs neighbour k of those queries as one 16-pixel block (lane j <-> query j), the pooled value is a
 // running maximum in registers -- no DPP reduction, and every lane stores its own query's row.
 template <int W>
-__global__ __launch_bounds__(W * 64) void upconv_lane_kernel(UpHArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void upconv_lane_kernel(UpHArgs a) {
   TraceScope trace_scope_(TK_UPCONV_LANE);
   constexpr int B1 = 8, B2 = 4;
   constexpr int W1 = layer_floats(1, B1);
@@ -341,7 +341,7 @@ struct UpPostArgs {
 };
 
 template <int NB2, int W>
-__global__ __launch_bounds__(W * 64) void upconv_lane_post_kernel(UpPostArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void upconv_lane_post_kernel(UpPostArgs a) {
   TraceScope trace_scope_(TK_UPCONV_LANE);
   constexpr int B1 = 8, B2 = 4;
   constexpr int W1 = layer_floats(1, B1), W2 = layer_floats(B1, B2), WP = layer_floats(B2 + NB2, 4);
@@ -424,7 +424,7 @@ struct CVHArgs {
 };
 
 template <int KP, int P, int W, int FMT = 0>
-__global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void cv_a1_h_kernel(CVHArgs a) {
   TraceScope trace_scope_(TK_CV_A1_H);
   constexpr int B1 = 8, B2 = 4, B3 = 4;
   constexpr int W1 = layer_floats(1, B1), W2 = layer_floats_any<FMT>(B1, B2), W3 = layer_floats_any<FMT>(B2, B3);
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(W * 64) void cv_a1_h_kernel(CVHArgs a) {
 }
 
 template <int KP, int P, int W, int FMT = 0>
-__global__ __launch_bounds__(W * 64) void cv_b_h_kernel(CVHArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void cv_b_h_kernel(CVHArgs a) {
   TraceScope trace_scope_(TK_CV_B_H);
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<FMT>(4, 8), W2 = layer_floats_any<FMT>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -578,7 +578,7 @@ __device__ __forceinline__ f32x4 geometry_block_std(const float *p, const float 
 }
 
 template <int W, bool V2>
-__global__ __launch_bounds__(W * 64) void cv_a_lane6_kernel(CVLaneArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void cv_a_lane6_kernel(CVLaneArgs a) {
   TraceScope trace_scope_(TK_CV_A2_LANE6);
   constexpr int P = 2, PASSES = 3;
   constexpr int A1 = layer_floats(1, 8), A2 = layer_floats(8, 4), A3 = layer_floats(4, 4);

@@ -106,7 +106,7 @@ struct UpconvArgs {
 };
 
 template <int KP, int P, int W>
-__global__ __launch_bounds__(W * 64) void upconv_kernel(UpconvArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void upconv_kernel(UpconvArgs a) {
   constexpr int NBI = 5, B1 = 8, B2 = 4;
   constexpr int W1 = layer_floats(NBI, B1), W2 = layer_floats(B1, B2);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -171,7 +171,7 @@ struct PointwiseArgs {
 // of layer 2 are its B operands -- with its tiles LDS resident beside the stack's; same routine, operands and k order as
 // linear_jobs_kernel: bit-identical rows.
 template <int NB0, int NB1, int NB2, int B1, int B2 /*0 = single layer*/, int P, int W, int BT = 0>
-__global__ __launch_bounds__(W * 64) void pointwise_kernel(PointwiseArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void pointwise_kernel(PointwiseArgs a) {
   TraceScope trace_scope_(TK_POINTWISE);
   constexpr int NBI = NB0 + NB1 + NB2;
   constexpr int W1 = layer_floats(NBI, B1);
@@ -251,7 +251,7 @@ struct CVArgs {
 
 // a1: [geo | centre feat (CB blocks) | gathered feat (CB blocks)] -> 128 -> 64 -> 64, stored per pixel.
 template <int CB, int KP, int P, int W>
-__global__ __launch_bounds__(W * 64) void cv_a1_kernel(CVArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void cv_a1_kernel(CVArgs a) {
   constexpr int NBI = 1 + 2 * CB, B1 = 8, B2 = 4, B3 = 4, C = 16 * CB;
   constexpr int W1 = layer_floats(NBI, B1), W2 = layer_floats(B1, B2), W3 = layer_floats(B2, B3);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(W * 64) void cv_a1_kernel(CVArgs a) {
 
 // a2: enc = mlp_conv_xyz_1(geo); w = softmax_k(mlp2_convs([enc | feat])); out = sum_k w * feat.
 template <int KP, int P, int W, int FMT = 0>
-__global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void cv_a2_kernel(CVArgs a) {
   TraceScope trace_scope_(TK_CV_A2);
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<FMT>(8, 8), W2 = layer_floats_any<FMT>(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(W * 64) void cv_a2_kernel(CVArgs a) {
 //           blocks: reduced in-lane across the blocks, then across the lane pair (one DPP step).
 // cv_a1 writes the per-pixel features densely as (B, S, 6, 64) for this kernel.
 template <int W, int FMT = 0>
-__global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void cv_a2_dense6_kernel(CVArgs a) {
   TraceScope trace_scope_(TK_CV_A2_DENSE6);
   constexpr int P = 3;
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats_any<FMT>(8, 8), W2 = layer_floats_any<FMT>(8, 4);
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(W * 64) void cv_a2_dense6_kernel(CVArgs a) {
 // running-maximum form of the softmax: (m, d, n) -> m' = max(m_a, m_b), d' = d_a e^(m_a-m') + d_b e^(m_b-m'), same
 // for n; out = n / d.  Same values as the direct form up to two extra roundings (1e-7 relative).
 template <int W>
-__global__ __launch_bounds__(W * 64) void cv_a2_lane6_kernel(CVArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void cv_a2_lane6_kernel(CVArgs a) {
   TraceScope trace_scope_(TK_CV_A2_LANE6);
   constexpr int P = 2, PASSES = 3;          // three passes of two neighbour blocks: fits 256 VGPRs without spills
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats(8, 8), W2 = layer_floats(8, 4);
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(W * 64) void cv_a2_lane6_kernel(CVArgs a) {
 // b: enc2 = mlp_conv_xyz_2(geo'); w = softmax_k(mlp3_convs([enc2 | centre feat | gathered first]));
 //    out = sum_k w * gathered first.  Candidates = the frame-1 points themselves (N == S).
 template <int CB, int KP, int P, int W>
-__global__ __launch_bounds__(W * 64) void cv_b_kernel(CVArgs a) {
+__global__ __launch_bounds__(W * 64, (W <= 4 ? 2 : 1)) void cv_b_kernel(CVArgs a) {
   constexpr int NBI = 4 + CB + 4, C = 16 * CB;
   constexpr int WX = layer_floats(1, 4), W1 = layer_floats(NBI, 8), W2 = layer_floats(8, 4);
   extern __shared__ __attribute__((aligned(16))) float lds_w[];
