@@ -38,6 +38,11 @@ __global__ __launch_bounds__(T) void probe(float *out, long long *rec, int reps,
       if (KIND == 15) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
       if (KIND == 16) asm volatile("v_mov_b32_dpp %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
       if (KIND == 17) asm volatile("v_max_i32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+      if (KIND == 18) asm volatile("v_add_f32_e64 %0, %0, |%0|" : "+v"(a[i]));               // x + |x| = 2 relu(x)
+      if (KIND == 19) asm volatile("v_max_i32 %0, 0, %0" : "+v"(a[i]));                        // relu_bits
+      if (KIND == 20) asm volatile("v_max_f32 %0, 0, %0" : "+v"(a[i]));
+      if (KIND == 21) asm volatile("v_mul_f32_e64 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(s));
+      if (KIND == 22) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
     }
   }
   float acc = 0.f;
@@ -105,5 +110,10 @@ int main() {
   run<13>("v_cmp + v_cndmask (pair)");
   run<16>("v_mov_b32_dpp row_ror");
   run<17>("v_max_i32_dpp row_ror");
+  run<18>("v_add_f32 x, x, |x| (e64)");
+  run<19>("v_max_i32 x, 0, x");
+  run<20>("v_max_f32 x, 0, x");
+  run<21>("v_mul_f32 ... clamp (e64)");
+  run<22>("v_exp_f32");
   return 0;
 }
