@@ -760,7 +760,7 @@ class FusedCostVolumeHoisted:
             idx_q = knn(kq, xyz2, xyz1)
         kp = self.kp
         merged = (kp == 6 and kq == 6 and self.wfmt == WFMT_F32 and self.wfmt_a2 == WFMT_F32
-                  and B * ((S + 15) // 16) >= int(os.environ.get("PWCLO_CV_MERGED_MIN", "1025"))
+                  and B * ((S + 15) // 16) >= int(os.environ.get("PWCLO_CV_MERGED_MIN", "512"))
                   and os.environ.get("PWCLO_LANE6", "1") != "0" and os.environ.get("PWCLO_CV_MERGED", "1") != "0")
         if merged:
             return self._merged(xyz1, xyz2, u, v, u2, idx_q, idx, taps, tap)
