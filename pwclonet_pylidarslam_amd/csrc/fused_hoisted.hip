@@ -700,6 +700,11 @@ static void launch_h(Kern kern, bool &attr_set, int lds_bytes, long long ntiles,
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W * 64), lds_bytes, current_stream(), a);
 }
 
+static int coarse_tiles_h() {   // fused_layers.hip: coarse_tiles()
+  static const int v = fh_tuning("PWCLO_COARSE_W4_TILES", 2047);
+  return v;
+}
+
 static long long tiles_h(int b, int s, int kp, int p) {
   return (long long)b * (((long long)s * kp + 16 * p - 1) / (16 * p));
 }
@@ -780,7 +785,7 @@ extern "C" void sa_fused_h_kernel_wrapper(int b, int n, int s, int k, int c1, in
   SAH_CASE(32, 32, 64, 16, false, 1, 16)    // psa_3
   SAH_CASE(64, 64, 128, 16, false, 1, 16)   // psa_4
   static const int coarse_w4 = fh_tuning("PWCLO_COARSE_W4", 1);
-  if (coarse_w4 && tiles_h(b, s, 16, 1) <= 2048) { SAH_CASE(128, 64, 64, 16, false, 1, 4) }   // flow_feature_encoding, coarse
+  if (coarse_w4 && tiles_h(b, s, 16, 1) <= coarse_tiles_h()) { SAH_CASE(128, 64, 64, 16, false, 1, 4) }   // flow_feature_encoding, coarse
   SAH_CASE(128, 64, 64, 16, false, 1, 16)   // flow_feature_encoding
 #undef SAH_CASE
   set_error(PWCLO_EINVAL, "sa_fused_h: no kernel for mlp=(%d,%d,%d) nsample=%d level0=%d", c1, c2, c3, k, (int)lvl0);
@@ -931,7 +936,7 @@ extern "C" void cv_fused_b_h_kernel_wrapper(int b, int s, int k, const float *xy
   static bool attr_s = false, attr3 = false, attr3_s = false;
   constexpr int lds3 = 4 * (layer_floats(1, 4) + layer_floats_bf3(4, 8) + layer_floats_bf3(8, 4));
   static const int coarse_w4 = fh_tuning("PWCLO_COARSE_W4", 1);
-  const bool small = coarse_w4 && tiles_h(b, s, 4, 1) <= 2048;
+  const bool small = coarse_w4 && tiles_h(b, s, 4, 1) <= coarse_tiles_h();
   constexpr int lds2 = 4 * (layer_floats(1, 4) + layer_floats_bf16(4, 8) + layer_floats_bf16(8, 4));
   static bool attr2 = false, attr2_s = false;
   PWCLO_REQUIRE_PACKED("cv_fused_b_h", wfmt, packed_floats, lds / 4, lds3 / 4, lds2 / 4);

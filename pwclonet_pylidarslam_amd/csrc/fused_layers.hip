@@ -766,6 +766,15 @@ static int fl_tuning(const char *name, int dflt) {   // PWCLO_FL_<NAME> override
   return e ? atoi(e) : dflt;
 }
 
+// Largest launch (in wave tiles) that still takes the 4-wave workgroup variants of the point-wise / coarse-level kernels.  Narrow
+// workgroups reach more CUs -- lower latency of a lone forward (batch 1: +7 %, batch 4: +5 %) -- but every workgroup stages the
+// stack's 100-160 KB of weights again, which costs CU-time: in the pipelined batch-32 run the launches of exactly 2048 tiles
+// (level-2 flow predictors) are better off wide (+0.3 %, profiles/r03/r03_v7_ab_coarse_w4.txt); smaller ones stay narrow.
+static int coarse_tiles() {
+  static const int v = fl_tuning("PWCLO_COARSE_W4_TILES", 2047);
+  return v;
+}
+
 template <int W, typename Kern, typename Args>
 static void launch_persistent(Kern kern, bool &attr_set, int lds_bytes, long long ntiles, const Args &a) {
   if (lds_bytes > 64 * 1024 && !attr_set) {
@@ -818,7 +827,7 @@ extern "C" void pointwise_fused_kernel_wrapper(int b, int s, int c0, int c1, int
     constexpr int lds = 4 * (layer_floats(NBI, A1 / 16) + (A2 > 0 ? layer_floats(A1 / 16, A2 / 16) : 0)); \
     /* few tiles (coarse levels): 4-wave workgroups spread them over 4x more CUs; a 16-wave        \
        workgroup would run 4 tiles back to back on each SIMD while most of the chip idles */        \
-    if (wide && fl_tuning("PWCLO_COARSE_W4", 1) && tiles_of(b, s, 1, 1) <= 2048)                    \
+    if (wide && fl_tuning("PWCLO_COARSE_W4", 1) && tiles_of(b, s, 1, 1) <= coarse_tiles())                  \
       launch_persistent<4>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 4>,      \
                            attr4, lds, tiles_of(b, s, 1, 1), a);                                    \
     else if (wide) launch_persistent<16>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 16>, \
@@ -859,7 +868,7 @@ extern "C" void pointwise_tail_fused_kernel_wrapper(int b, int s, int c0, int c1
     static_assert(lds <= 160 * 1024, "stack and tail must fit the 160 KiB of LDS");                 \
     PWCLO_REQUIRE(tail_floats == layer_floats(A2 / 16, AT / 16), "pointwise_tail_fused: packed tail holds %d floats, needs %d", \
                   tail_floats, layer_floats(A2 / 16, AT / 16));                                     \
-    if (fl_tuning("PWCLO_COARSE_W4", 1) && tiles_of(b, s, 1, 1) <= 2048)                            \
+    if (fl_tuning("PWCLO_COARSE_W4", 1) && tiles_of(b, s, 1, 1) <= coarse_tiles())                        \
       launch_persistent<4>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 4, AT / 16>, \
                            attr4, lds, tiles_of(b, s, 1, 1), a);                                    \
     else launch_persistent<16>(pointwise_kernel<C0 / 16, C1 / 16, C2 / 16, A1 / 16, A2 / 16, 1, 16, AT / 16>, \

@@ -810,7 +810,7 @@ class FusedCostVolumeHoisted:
         B, S, _ = xyz1.shape
         dev, k, c = xyz1.device, self.nsample, self.c
         out = torch.empty((B, S, 64), dtype=torch.float32, device=dev)
-        _lib.annotate(family="mlp", kernel=_kname("cv_b_h_kernel<4, 1, %d>" % (4 if B * ((S * 4 + 15) // 16) <= 2048 else 16), self.wfmt),
+        _lib.annotate(family="mlp", kernel=_kname("cv_b_h_kernel<4, 1, %d>" % (4 if B * ((S * 4 + 15) // 16) <= int(os.environ.get("PWCLO_COARSE_W4_TILES", "2047")) else 16), self.wfmt),
                       flops=2.0 * B * S * k * (self.macs_b - (c + 64) * 128),
                       bytes=4.0 * B * (S * k * (1 + 3 + 128 + 64) + S * (3 + 128 + 64)))
         _lib.call("cv_fused_b_h_kernel_wrapper", dev, B, S, k, _p(xyz1), _p(u2), _p(v2), _p(first), _p(idx),
